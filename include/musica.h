@@ -1,0 +1,295 @@
+/*
+ * musica.h — C ABI of libmusica_hip.so, the MI355X-native replacement for the
+ * MUSICA Laplacian-pyramid contrast-amplification path of the reference
+ * (class VulkanProcessing, include/vk_processing.h:26-356 of the reference;
+ * dispatch script src/vk_processing.cpp:2104-2601; shaders/X.comp).
+ *
+ * The reference has no extern "C" surface: its harness crosses a process
+ * boundary (`maverick-standalone <raw> <bmp>`, test/standalone/main.cpp:30-87)
+ * that makes four C++ calls on VulkanProcessing. Each entry point below names
+ * the C++ member it replaces. `bool` becomes `int` (1 = ok, 0 = failed) so the
+ * reference's truthiness convention (ASSERT_MSG(call, msg)) carries over; on
+ * failure a message "MUSICA ERROR: ..." is written to stderr, mirroring
+ * `fprintf(stderr, "VK STATE ERROR: %s\n")` (src/vk_processing.cpp:14-18), and
+ * is retrievable with musica_last_error().
+ *
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ * All images are square (the reference never handles W != H,
+ * src/vk_processing.cpp:2630-2631), single channel, row-major, dense when they
+ * cross the ABI (the library keeps its own pitched layout in HBM).
+ */
+#ifndef MUSICA_H
+#define MUSICA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUSICA_ABI_VERSION 1
+
+/* Hard-coded constants of the reference. */
+#define MUSICA_MAX_LEVELS 16          /* reference: 12 + 1 clear buffers, vk_processing.h:67 */
+#define MUSICA_MIN_LEVELS 4           /* cnrLevel = coarserLevelsStart = 3 must exist, vk_processing.h:28-29 */
+#define MUSICA_NOISE_BINS 2048        /* vk_processing.h:37, noise_hist.comp:6 */
+#define MUSICA_GRAD_BINS 1024         /* vk_processing.h:38, gradation_histogram.comp:6 */
+#define MUSICA_MAX_POINTS 256         /* contrast_curve_generate.comp:5 */
+#define MUSICA_CNR_LEVEL 3            /* vk_processing.h:29 */
+#define MUSICA_COARSER_LEVELS_START 3 /* vk_processing.h:28 */
+#define MUSICA_OUT_MARGIN 10          /* src/vk_processing.cpp:2607 */
+#define MUSICA_CLAHE_TILES 4          /* clahe_histogram.comp:4 */
+#define MUSICA_CLAHE_BINS 256         /* clahe_grad_curve.comp:4 */
+
+/* T1: struct HistogramMaxPoint, vk_processing.h:123-126. */
+typedef struct musica_hist_max_point {
+    uint32_t maxValue;
+    uint32_t maxBin;
+} musica_hist_max_point;
+
+/* T2: struct ContrastParameters, vk_processing.h:135-138. */
+typedef struct musica_contrast_params {
+    float lowContrastFactor;
+    float highContrastFactor;
+} musica_contrast_params;
+
+typedef struct musica_point {
+    float x;
+    float y;
+} musica_point;
+
+/* T3: struct ContrastCurveObj, vk_processing.h:141-149 (2052 bytes). */
+typedef struct musica_contrast_curve {
+    musica_point points[MUSICA_MAX_POINTS];
+    uint32_t pointsCount;
+} musica_contrast_curve;
+
+/* T4: struct NoiseReductionParams, vk_processing.h:112-117. */
+typedef struct musica_nr_params {
+    float lowCnr;
+    float lowFactor;
+    float highCnr;
+    float highFactor;
+} musica_nr_params;
+
+/* T5: struct GradCurveObj, vk_processing.h:215-222 (2064 bytes). */
+typedef struct musica_grad_curve {
+    musica_point points[MUSICA_MAX_POINTS];
+    uint32_t pointsCount;
+    float t0;
+    float ta;
+    float t1;
+} musica_grad_curve;
+
+/* Per-image summary gathered across GPUs by the batch driver. */
+typedef struct musica_stats {
+    uint32_t image_id;        /* index inside the batch handed to execute */
+    float min_sqrt;           /* final texel of the min chain (min_reduce.comp) */
+    float max_sqrt;           /* final texel of the max chain (img_max_reduce.comp) */
+    uint32_t noise_max_bin[4];   /* HistogramMaxPoint.maxBin of levels 0..3 */
+    uint32_t noise_max_value[4]; /* HistogramMaxPoint.maxValue of levels 0..3 */
+    uint32_t grad_max_bin;
+    uint32_t grad_max_value;
+    float mean_cnr;           /* mean(cnr image) * 256: what test/mean_cnr/script.py:13-24 prints */
+    float t0, ta, t1;         /* gradation window, gradation_curve_generate.comp:54-144 */
+} musica_stats;
+
+/* Flags for musica_params.flags */
+#define MUSICA_FLAG_CLAHE      0x1u /* CLAHE gradation (reference: #ifdef ENABLE_CLAHE, vk_processing.h:13) */
+#define MUSICA_FLAG_NO_GRAPH   0x2u /* launch kernels eagerly instead of replaying a captured hipGraph */
+
+/* Construction parameters: the reference hard-wires these as literals
+ * (imageSize = 3072 in test/standalone/main.cpp:31; L = ceil(log2 N) in
+ * src/vk_processing.cpp:1989). */
+typedef struct musica_params {
+    uint32_t image_size; /* N; N >= 16 */
+    uint32_t levels;     /* L; 0 => ceil(log2 N) (reference rule); else 4 <= L <= ceil(log2 N) */
+    uint32_t batch;      /* images per execute call, 0 => 1 (reference: 1) */
+    int32_t device;      /* HIP device ordinal */
+    uint32_t flags;      /* MUSICA_FLAG_* */
+} musica_params;
+
+typedef struct musica_ctx musica_ctx;
+
+/* Image kinds addressable by musica_get_image / musica_debug_set_image.
+ * `level` is the pyramid level whose grid the image lives on. */
+typedef enum musica_image_kind {
+    MUSICA_IMG_NORMALIZED = 0,   /* normalizedImageState, N x N (level must be 0) */
+    MUSICA_IMG_DOWNSAMPLED = 1,  /* downsampledImageStates[level], side S_{level+1} */
+    MUSICA_IMG_BANDPASS = 2,     /* bandpassImageStates[level], side S_level */
+    MUSICA_IMG_SDEV = 3,         /* sdevImageStates[level] (levels 0..3), side S_level */
+    MUSICA_IMG_CNR = 4,          /* cnrImageState, side S_3 (level must be 3) */
+    MUSICA_IMG_EXPAND = 5,       /* expandImageStates[L-1-level]: reconstruction at `level`, side S_level */
+    MUSICA_IMG_GRADED = 6,       /* gradedImageState, N x N (level must be 0) */
+    MUSICA_IMG_RELEVANT = 7,     /* relevantImageState, N x N; recomputed on demand (not stored on the hot path) */
+    MUSICA_IMG_LOWPASS = 8,      /* lowpassImageStates[level]; recomputed on demand */
+    MUSICA_IMG_EXP_BANDPASS = 9, /* band after contrast curve (+ noise reduction on levels 0,1) as fed to img_addition; recomputed on demand */
+    MUSICA_IMG_SQRT = 10,        /* sqrtImageState, N x N; recomputed on demand */
+    MUSICA_IMG_CLAHE_GRADED = 11, /* claheGradedImageState, N x N (only with MUSICA_FLAG_CLAHE; src/vk_processing.cpp:432-438) */
+    MUSICA_IMG_KIND_COUNT = 12
+} musica_image_kind;
+
+/* Pipeline stages runnable one at a time through musica_debug_run_stage
+ * (kernel-level parity tests inject an input with musica_debug_set_image and
+ * run exactly one stage). Names follow the per-stage timing line of the
+ * reference (src/vk_processing.cpp:2585-2595). */
+typedef enum musica_stage {
+    MUSICA_STAGE_NORM = 0,   /* sqrt, min/max chains, normalize        (.cpp:2182-2222) */
+    MUSICA_STAGE_REDUCE = 1, /* smooth, downsample, upsample, smooth_upsampled, difference (.cpp:2233-2273) */
+    MUSICA_STAGE_ANALYSIS = 2, /* sdev, noise_hist, hist_max, contrast_curve_generate, cnr (.cpp:2284-2357) */
+    MUSICA_STAGE_EXPAND = 3, /* contrast apply, noise reduction, upsample, smooth_upsampled, addition (.cpp:2361-2431) */
+    MUSICA_STAGE_GRADATION = 4, /* relevant, grad hist, hist max, curve generate, curve apply (.cpp:2456-2518) */
+    MUSICA_STAGE_COUNT = 5
+} musica_stage;
+
+/* ---- lifecycle ------------------------------------------------------- */
+
+/* Replaces: VulkanProcessing::VulkanProcessing(VulkanState*) + bool init(uint32_t imageSize,
+ * std::vector<VkImageView>*) (vk_processing.h:281-288, src/vk_processing.cpp:1984-2020).
+ * Allocates every device buffer once; returns NULL on failure. */
+musica_ctx* musica_create(const musica_params* params);
+
+/* Replaces: bool VulkanProcessing::cleanup() (src/vk_processing.cpp:2647-2651). Frees everything. */
+void musica_destroy(musica_ctx* ctx);
+
+/* Replaces: uint32_t getImageSize() (vk_processing.h:355). */
+uint32_t musica_get_image_size(const musica_ctx* ctx);
+uint32_t musica_get_levels(const musica_ctx* ctx);
+uint32_t musica_get_batch(const musica_ctx* ctx);
+/* Side of pyramid level `level` (S_0 = N, S_{i+1} = ceil(S_i / 2); level may be L for the residual). */
+uint32_t musica_get_level_size(const musica_ctx* ctx, uint32_t level);
+
+/* ---- the hot path ---------------------------------------------------- */
+
+/* Replaces: bool VulkanProcessing::execute(const uint16_t* imageData) (src/vk_processing.cpp:2104-2601).
+ * `pixels`: batch * N * N host uint16, row-major, borrowed for the call
+ * (H2D copy inside, as vk_state.cpp:313-342 does). Synchronous: returns after
+ * the device finished, like the final vkWaitForFences (.cpp:2535-2536). */
+int musica_execute(musica_ctx* ctx, const uint16_t* pixels);
+
+/* Same pipeline with the input already resident in HBM: `d_pixels` is a device
+ * pointer to batch * N * N uint16 (dense). Enqueues on the ctx stream and
+ * returns without waiting; pair with musica_sync(). */
+int musica_execute_device(musica_ctx* ctx, const uint16_t* d_pixels);
+
+/* Uploads host pixels into the ctx-owned resident input buffer and returns its
+ * device pointer (for musica_execute_device). */
+int musica_upload(musica_ctx* ctx, const uint16_t* pixels);
+const uint16_t* musica_input_device_ptr(musica_ctx* ctx);
+
+/* Blocks until everything enqueued on the ctx stream has finished. */
+int musica_sync(musica_ctx* ctx);
+
+/* ---- results --------------------------------------------------------- */
+
+/* D2H of gradedImageState (f32, batch * N * N, dense) — the image
+ * saveOutImage reads back (src/vk_processing.cpp:2609-2621). */
+int musica_get_graded(musica_ctx* ctx, float* dst);
+
+/* Replaces: bool VulkanProcessing::saveOutImage(std::string) (src/vk_processing.cpp:2603-2645):
+ * crop MUSICA_OUT_MARGIN on every side, (uint8_t)(255.0f * v), 24-bpp bottom-up
+ * BMP byte-identical to stbi_write_bmp(comp = 1) (stb_image_write.h:492-500).
+ * `image_index` selects the image of the batch (reference: 0). */
+int musica_save_out_image(musica_ctx* ctx, uint32_t image_index, const char* path);
+
+/* The 8-bit cropped pixels saveOutImage would write, side N - 20, top-down rows. */
+int musica_get_out_pixels(musica_ctx* ctx, uint32_t image_index, uint8_t* dst);
+
+/* One dense f32 image of one batch entry; side = musica_image_side(kind, level). */
+int musica_get_image(musica_ctx* ctx, uint32_t image_index, musica_image_kind kind, uint32_t level, float* dst);
+uint32_t musica_image_side(const musica_ctx* ctx, musica_image_kind kind, uint32_t level);
+
+/* Integer / small-struct state (bit-exact parity objects). */
+int musica_get_noise_hist(musica_ctx* ctx, uint32_t image_index, uint32_t level, uint32_t* dst /*2048*/);
+int musica_get_grad_hist(musica_ctx* ctx, uint32_t image_index, uint32_t* dst /*1024*/);
+int musica_get_noise_hist_max(musica_ctx* ctx, uint32_t image_index, uint32_t level, musica_hist_max_point* dst);
+int musica_get_grad_hist_max(musica_ctx* ctx, uint32_t image_index, musica_hist_max_point* dst);
+int musica_get_contrast_curve(musica_ctx* ctx, uint32_t image_index, uint32_t level, musica_contrast_curve* dst);
+int musica_get_grad_curve(musica_ctx* ctx, uint32_t image_index, musica_grad_curve* dst);
+int musica_get_contrast_params(musica_ctx* ctx, uint32_t level, musica_contrast_params* dst);
+int musica_get_nr_params(musica_ctx* ctx, uint32_t level /*0..2*/, musica_nr_params* dst);
+int musica_get_minmax(musica_ctx* ctx, uint32_t image_index, float* min_sqrt, float* max_sqrt);
+int musica_get_stats(musica_ctx* ctx, uint32_t image_index, musica_stats* dst);
+/* CLAHE state (only with MUSICA_FLAG_CLAHE): 4*4*256 u32 histograms [tx][ty][bin], 4*4*256 curve points. */
+int musica_get_clahe_hist(musica_ctx* ctx, uint32_t image_index, uint32_t* dst);
+int musica_get_clahe_curves(musica_ctx* ctx, uint32_t image_index, musica_point* dst);
+
+/* Replaces: bool VulkanProcessing::debugProcess() (src/vk_processing.cpp:2661-2809): writes
+ * norm.bmp, red_bandpass_i.bmp, red_lowpass_i.bmp, sdev.bmp, cnr.bmp,
+ * exp_bandpass_i.bmp, exp_lowpass_i.bmp, relevant.bmp, graded.bmp (same
+ * quantisation as VulkanState::downloadAndSaveImage, src/vk_state.cpp:809-855)
+ * into `dir`, plus noise_hist.csv / grad_hist.csv / curves as CSV instead of
+ * the rendered RGBA plots. */
+int musica_debug_process(musica_ctx* ctx, uint32_t image_index, const char* dir);
+
+/* ---- test / profiling hooks ------------------------------------------ */
+
+/* Overwrites one stored intermediate of one batch entry (dense f32 in). Only
+ * kinds the hot path keeps resident are accepted. */
+int musica_debug_set_image(musica_ctx* ctx, uint32_t image_index, musica_image_kind kind, uint32_t level, const float* src);
+/* Runs exactly one stage of the dispatch script on the current device state. */
+int musica_debug_run_stage(musica_ctx* ctx, musica_stage stage);
+
+/* Per-kernel device timing with HIP events on the ctx stream.
+ * musica_profile_enable(ctx, 1) makes every later execute bracket each kernel
+ * family with events (eager launches); musica_profile_get returns the mean
+ * duration in microseconds and the launch count since the last reset. */
+typedef enum musica_kernel_id {
+    MUSICA_KERNEL_MINMAX = 0,
+    MUSICA_KERNEL_NORMALIZE = 1,
+    MUSICA_KERNEL_REDUCE_L0 = 2,   /* fused 5-tap smooth + 2x downsample at level 0 (the metric kernel) */
+    MUSICA_KERNEL_REDUCE_REST = 3, /* same kernel, levels >= 1 */
+    MUSICA_KERNEL_BAND_L0 = 4,     /* fused upsample + smooth x4 + difference at level 0 */
+    MUSICA_KERNEL_BAND_REST = 5,
+    MUSICA_KERNEL_SDEV_HIST = 6,
+    MUSICA_KERNEL_CURVES = 7,
+    MUSICA_KERNEL_CNR = 8,
+    MUSICA_KERNEL_EXPAND_L0 = 9,   /* fused contrast apply + NR + upsample + smooth x4 + addition at level 0 */
+    MUSICA_KERNEL_EXPAND_REST = 10,
+    MUSICA_KERNEL_GRAD_HIST = 11,
+    MUSICA_KERNEL_GRAD_CURVE = 12,
+    MUSICA_KERNEL_GRAD_APPLY = 13,
+    MUSICA_KERNEL_COUNT = 14
+} musica_kernel_id;
+int musica_profile_enable(musica_ctx* ctx, int enabled);
+int musica_profile_reset(musica_ctx* ctx);
+int musica_profile_get(musica_ctx* ctx, musica_kernel_id id, double* mean_us, uint64_t* launches);
+
+/* Stand-alone launch of the metric kernel (fused smooth + downsample) on a
+ * side x side f32 image owned by the caller in device memory (pitch in floats,
+ * multiple of 4). Used by bench.py to time the kernel at 4096 x 4096 and by the
+ * kernel-level parity tests. d_out has side ceil(side/2), pitch out_pitch. */
+int musica_k_reduce(musica_ctx* ctx, const float* d_in, uint32_t side, uint32_t in_pitch,
+                    float* d_out, uint32_t out_pitch, uint32_t batch);
+/* Times `iters` back-to-back launches of the above with HIP events on the ctx
+ * stream; returns mean microseconds per launch in *mean_us. */
+int musica_k_reduce_timed(musica_ctx* ctx, const float* d_in, uint32_t side, uint32_t in_pitch,
+                          float* d_out, uint32_t out_pitch, uint32_t batch, uint32_t iters, double* mean_us);
+
+/* Raw device memory helpers so callers without a HIP binding (ctypes tests,
+ * bench.py) can stage buffers for the two functions above. */
+void* musica_device_alloc(musica_ctx* ctx, size_t bytes);
+void musica_device_free(musica_ctx* ctx, void* d_ptr);
+int musica_memcpy_h2d(musica_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int musica_memcpy_d2h(musica_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
+/* ---- file formats (host only, no GPU needed) -------------------------- */
+
+/* Raw reader of test/standalone/main.cpp:54-75: file = 256-byte header
+ * (ignored) + N*N little-endian uint16, size must match exactly. */
+int musica_read_raw(const char* path, uint32_t image_size, uint16_t* dst);
+/* 24-bpp BMP writer byte-identical to stbi_write_bmp(path, w, h, 1, data). */
+int musica_write_bmp_gray(const char* path, uint32_t w, uint32_t h, const uint8_t* data);
+
+/* ---- misc ------------------------------------------------------------ */
+const char* musica_last_error(void);
+uint32_t musica_abi_version(void);
+/* Number of HIP devices visible; 0 when there is none (never falls back to a CPU path). */
+int musica_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MUSICA_H */

@@ -1,0 +1,410 @@
+"""Analytic known-answer tests that pin the CPU oracle to the shader text.
+
+The reference ships no golden vectors for this path ("parity
+unpinned"), so each test below derives its expected value in closed form from
+the cited shader lines rather than from a recorded output.
+"""
+import numpy as np
+import pytest
+
+W = np.array([0.1, 0.25, 0.3, 0.25, 0.1], dtype=np.float32)  # img_smooth.comp:23-30
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+# (1) sum(w) = 1 => smoothing a constant returns it, borders included (S >= 3)
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("side", [3, 4, 5, 8, 17, 64])
+def test_smooth_constant(ob, order, side):
+    a = np.full((side, side), 0.625, dtype=np.float32)
+    out = ob.k_smooth(a, order)
+    assert np.abs(out - 0.625).max() <= 2e-7
+
+
+# (2) centred impulse => outer(w, w); reference order gives exactly w[m]*w[n]
+@pytest.mark.parametrize("order", [0, 1])
+def test_smooth_impulse(ob, order):
+    a = np.zeros((9, 9), dtype=np.float32)
+    a[4, 4] = 1.0
+    out = ob.k_smooth(a, order)
+    expect = np.zeros((9, 9), dtype=np.float32)
+    expect[2:7, 2:7] = np.outer(W, W)  # out(y, x) = w[x-idx] * w[y-idx], symmetric
+    if order == 0:
+        assert np.array_equal(out, expect)
+    else:
+        assert np.abs(out - expect).max() <= 1e-8
+
+
+def test_smooth_reflect101_border(ob):
+    # mirror(-1) = 1, mirror(-2) = 2, mirror(S) = S-2 (img_smooth.comp:10-16): a ramp in x
+    # stays a ramp in the interior and is pulled towards the inside at the border.
+    s = 8
+    a = np.tile(np.arange(s, dtype=np.float32), (s, 1))
+    out = ob.k_smooth(a, 0)
+    np.testing.assert_allclose(out[:, 2:6], a[:, 2:6], atol=1e-6)
+    # x = 0: taps at x = 2,1,0,1,2 -> 0.1*2 + 0.25*1 + 0 + 0.25*1 + 0.1*2 = 0.9
+    np.testing.assert_allclose(out[:, 0], 0.9, atol=1e-6)
+    # x = 1: taps 1,0,1,2,3 -> 0.1 + 0 + 0.3 + 0.5 + 0.3 = 1.2
+    np.testing.assert_allclose(out[:, 1], 1.2, atol=1e-6)
+
+
+def test_smooth_tiny_sizes_leak_zero(ob):
+    # S = 2: mirror(-2) = 2 and mirror(3) = -1 are out of range (the clamp is a no-op, Q3) -> 0 (Q1)
+    a = np.ones((2, 2), dtype=np.float32)
+    out = ob.k_smooth(a, 0)
+    # per axis at x = 0: taps -2->2 (OOB 0), -1->1, 0, 1, 2->0: 0 + .25 + .3 + .25 + .1 = 0.9
+    #          at x = 1: taps -1->1, 0, 1, 2->0, 3->-1 (OOB): .1 + .25 + .3 + .25 + 0 = 0.9
+    np.testing.assert_allclose(out, 0.81, atol=1e-6)
+
+
+# (3) zero-insert + x4 smooth of a constant returns it => all bands of a constant image are 0
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("side", [8, 9, 16, 31])
+def test_upsample_smooth_constant(ob, order, side):
+    cs = (side + 1) // 2
+    c = np.full((cs, cs), 0.375, dtype=np.float32)
+    up = ob.k_upsample(c, side)
+    assert up[1::2, :].max() == 0 and up[:, 1::2].max() == 0
+    low = ob.k_smooth_upsampled(up, order)
+    if side % 2 == 0:
+        # even side: the last (odd) column/row mirrors onto an even texel -> still exact
+        np.testing.assert_allclose(low, 0.375, atol=2e-7)
+    else:
+        np.testing.assert_allclose(low, 0.375, atol=2e-7)
+
+
+def test_polyphase_equivalence(ob):
+    # even outputs <- {.1,.3,.1} x2 on k-1,k,k+1 ; odd outputs <- {.25,.25} x2 on k,k+1
+    rng = _rng(0)
+    cs, side = 16, 32
+    c = rng.random((cs, cs), dtype=np.float32)
+    low = ob.k_smooth_upsampled(ob.k_upsample(c, side), 0)
+
+    def poly1d(v):  # v: (cs,) -> (side,)
+        out = np.zeros(side, dtype=np.float64)
+        for k in range(cs):
+            km1 = k - 1 if k >= 1 else 1          # mirror(-2) = 2 -> coarse 1
+            kp1 = k + 1 if k + 1 < cs else cs - 1  # even side: mirror(S) = S-2 -> coarse cs-1
+            out[2 * k] = 2 * (0.1 * v[km1] + 0.3 * v[k] + 0.1 * v[kp1])
+            out[2 * k + 1] = 2 * (0.25 * v[k] + 0.25 * v[kp1])
+        return out
+    tmp = np.stack([poly1d(c[r].astype(np.float64)) for r in range(cs)])          # (cs, side)
+    full = np.stack([poly1d(tmp[:, x]) for x in range(side)], axis=1)             # (side, side)
+    np.testing.assert_allclose(low, full, atol=2e-6)
+
+
+# (4) with all gains 1 the expand output equals the normalized input (perfect reconstruction)
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("side,levels", [(64, 4), (96, 5), (100, 6), (129, 7)])
+def test_perfect_reconstruction(ob, order, side, levels):
+    rng = _rng(side)
+    norm = rng.random((side, side), dtype=np.float32)
+    sizes = [side]
+    for _ in range(levels):
+        sizes.append((sizes[-1] + 1) // 2)
+    ins, bands = [norm], []
+    for i in range(levels):
+        sm = ob.k_smooth(ins[i], order)
+        down = ob.k_downsample(sm)
+        low = ob.k_smooth_upsampled(ob.k_upsample(down, sizes[i]), order)
+        bands.append(ins[i] - low)
+        ins.append(down)
+    rec = ins[levels]
+    for i in reversed(range(levels)):
+        low = ob.k_smooth_upsampled(ob.k_upsample(rec, sizes[i]), order)
+        rec = low + bands[i]
+    assert np.abs(rec - norm).max() <= 4e-6
+
+
+# (5) min / max chains
+@pytest.mark.parametrize("side", [64, 512, 100, 256, 24, 16, 72])
+def test_minmax_chain(ob, side):
+    rng = _rng(side)
+    px = rng.integers(900, 60000, size=(side, side), dtype=np.uint16)
+    sq = ob.k_sqrt(px)
+    mx = ob.chain(ob.k_max_reduce, sq)
+    mn = ob.chain(ob.k_min_reduce, sq)
+    assert mx == float(np.floor(np.sqrt(np.float32(px.max()))))   # Q4: floor at every link, monotone
+    is_pow8 = side in (8, 64, 512, 4096)
+    if is_pow8:
+        assert mn == float(np.floor(np.sqrt(np.float32(px.min()))))
+    else:
+        assert mn == 0.0  # a partial 8x8 block somewhere in the chain reads OOB zeros (Q1 + min_reduce.comp:19-27)
+
+
+def test_normalize_unclamped(ob):
+    a = np.array([[44.2, 246.9], [100.0, 44.0]], dtype=np.float32)
+    out = ob.k_normalize(a, 44.0, 246.0)
+    assert out[0, 1] > 1.0          # max was floored; clamp at img_normalize.comp:27 is a no-op
+    assert out[1, 1] == 0.0
+    np.testing.assert_allclose(out[1, 0], (100.0 - 44.0) / 202.0, rtol=1e-7)
+
+
+# (6) histogram argmax: first (lowest-index) maximum wins; empty -> (0, 0)
+def test_histogram_max_tiebreak(ob):
+    h = np.zeros(2048, dtype=np.uint32)
+    assert ob.k_histogram_max(h) == (0, 0)
+    h[[7, 300, 1999]] = 41
+    h[299] = 40
+    assert ob.k_histogram_max(h) == (41, 7)
+
+
+# (7) contrast curve points in closed form
+def test_contrast_curve_constant_levels(ob):
+    for L in (5, 6, 8, 12):
+        for lvl in range(3, L):
+            low, high = ob.host_contrast_params(lvl, L)
+            assert low == 1.0
+            expect = np.float32(0.2) ** np.float32((lvl - 3) / np.float32(L - 4)) if L > 4 else 1.0
+            np.testing.assert_allclose(high, expect, rtol=2e-7)
+            c = ob.k_contrast_curve_generate(123, low, high)
+            assert c.pointsCount == 2
+            assert (c.points[0].x, c.points[0].y, c.points[1].x, c.points[1].y) == (0.0, high, 1.0, high)
+    # level 4 of L levels: 0.2^(1/(L-4))
+    np.testing.assert_allclose(ob.host_contrast_params(4, 8)[1], 0.2 ** 0.25, rtol=2e-7)
+    # L = 4: exponent 0/0 in the reference -> restated as factor 1
+    assert ob.host_contrast_params(3, 4) == (1.0, 1.0)
+
+
+def test_contrast_curve_low_levels(ob):
+    low0 = ob.host_contrast_params(0, 8)[0]
+    assert low0 == 3.0
+    np.testing.assert_allclose(ob.host_contrast_params(1, 8)[0], 3.0 ** (2.0 / 3.0), rtol=2e-7)
+    np.testing.assert_allclose(ob.host_contrast_params(2, 8)[0], 3.0 ** (1.0 / 3.0), rtol=2e-7)
+    max_bin = 48
+    c = ob.k_contrast_curve_generate(max_bin, 3.0, 1.0)
+    assert c.pointsCount == 33
+    pts = c.as_array().astype(np.float64)
+    p = max_bin / 2048.0 * 0.1
+
+    def bez(s, m, e):
+        t = np.arange(11) / 10.0
+        return ((1 - t) ** 2)[:, None] * s + (2 * t * (1 - t))[:, None] * m + (t ** 2)[:, None] * e
+    expect = np.concatenate([
+        bez(np.array([0, 1.0]), np.array([0.8 * p, 3.0]), np.array([p, 3.0])),
+        bez(np.array([p, 3.0]), np.array([1.2 * p, 3.0]), np.array([1.4 * p, 2.4])),
+        bez(np.array([1.4 * p, 2.4]), np.array([2 * p, 1.0]), np.array([1.0, 1.0]))])
+    np.testing.assert_allclose(pts, expect, atol=1e-6)
+
+
+# (8) noise reduction at cnr = lowCnr gives lowF + 3m (m * c, not m * (c - lowCnr))
+def test_noise_reduction_formula(ob):
+    params = ob.host_nr_params(0)
+    assert params == (3.0, np.float32(0.6), 9.0, np.float32(1.2))
+    p1 = ob.host_nr_params(1)
+    np.testing.assert_allclose(p1[1], 0.6 + 0.4 / 3, rtol=1e-6)
+    np.testing.assert_allclose(p1[3], 1.2 - 0.2 / 3, rtol=1e-6)
+    band = np.ones((16, 16), dtype=np.float32)
+    for c, expect in [(2.0, 0.6), (3.0, 0.6 + 3 * 0.1), (6.0, 0.6 + 6 * 0.1), (9.0, 0.6 + 9 * 0.1), (9.5, 1.2)]:
+        cnr = np.full((2, 2), c / 256.0, dtype=np.float32)
+        out = ob.k_noise_reduction(band, cnr, params)
+        np.testing.assert_allclose(out, expect, rtol=1e-6)
+
+
+def test_noise_reduction_scale(ob):
+    # scaleFactor = uint(ceil(S_l / float(S_3))), cnr sampled at (x / scale, y / scale)
+    band = np.ones((25, 25), dtype=np.float32)
+    cnr = np.zeros((13, 13), dtype=np.float32)
+    cnr[3, 5] = 20.0 / 256.0   # > highCnr
+    out = ob.k_noise_reduction(band, cnr, ob.host_nr_params(2))
+    hf = ob.host_nr_params(2)[3]
+    lf = ob.host_nr_params(2)[1]
+    expect = np.full((25, 25), lf, dtype=np.float32)
+    expect[6:8, 10:12] = hf    # scale = ceil(25 / 13) = 2
+    np.testing.assert_array_equal(out, expect)
+
+
+# (9) contrast apply: gain = high for sdev in [0, 1], 0 for sdev > 1 or NaN
+def test_contrast_apply_constant_curve(ob):
+    c = ob.k_contrast_curve_generate(0, 1.0, 0.5)
+    band = np.full((4, 4), 2.0, dtype=np.float32)
+    sdev = np.array([[0.0, 0.3, 1.0, 1.0000001]] * 4, dtype=np.float32)
+    sdev[3, 0] = np.nan
+    out = ob.k_contrast_curve_apply(band, sdev, c)
+    np.testing.assert_array_equal(out[0], [1.0, 1.0, 1.0, 0.0])
+    assert out[3, 0] == 0.0
+
+
+def test_get_y_first_match_and_fallthrough(ob):
+    pts = [(0.0, 1.0), (0.5, 3.0), (0.5, 5.0), (1.0, 7.0)]
+    assert ob.get_y(pts, 0.0) == 1.0
+    assert ob.get_y(pts, 0.25) == 2.0
+    assert ob.get_y(pts, 0.5) == 3.0       # interval [0, .5] matches before the equality at index 1
+    assert ob.get_y(pts, 0.75) == 6.0
+    assert ob.get_y(pts, 1.0) == 7.0
+    assert ob.get_y(pts, 1.5) == 0.0
+    assert ob.get_y(pts, -0.1) == 0.0
+
+
+# (10) `break` (noise_hist) vs `return` (gradation_histogram) on a hand-built 16x16 tile with one zero
+def test_noise_hist_break_semantics(ob):
+    side = 512
+    sd = np.zeros((side, side), dtype=np.float32)
+    v = np.float32(0.05)  # bin = int(0.05 / 0.1 * 2048 + 0.5) = 1024
+    sd[0:16, 0:16] = v
+    sd[5, 3] = 0.0        # (x = 3, y = 5): column m = 3 stops at n = 5, other columns unaffected
+    h = ob.k_noise_hist(sd, 1)
+    assert h.sum() == 15 * 16 + 5
+    assert h[1024] == 15 * 16 + 5
+    # out-of-range value also breaks; bin 0 breaks; value exactly 0.1 -> bin 2048 is dropped but does not break
+    sd2 = np.zeros((side, side), dtype=np.float32)
+    sd2[0:16, 0] = v
+    sd2[2, 0] = 0.2       # a > 1 -> break at n = 2
+    sd2[0:16, 1] = v
+    sd2[4, 1] = 1e-6      # bin 0 -> break at n = 4
+    sd2[0:16, 2] = v
+    sd2[7, 2] = 0.1       # adjusted == 1.0 -> bin 2048 dropped (Q1), loop continues
+    h2 = ob.k_noise_hist(sd2, 1)
+    assert h2[1024] == 2 + 4 + 15 and h2.sum() == 21
+
+
+def test_noise_hist_coverage_is_full_res_integer_division(ob):
+    # groups = imageSize / 512 (integer division, src/vk_processing.cpp:2293-2295): N = 1000 -> 1 group -> 512 px
+    side = 1000
+    sd = np.full((side, side), 0.05, dtype=np.float32)
+    h = ob.k_noise_hist(sd, side // 512)
+    assert h[1024] == 512 * 512
+
+
+def test_gradation_hist_return_semantics(ob):
+    side = 512
+    img = np.zeros((side, side), dtype=np.float32)
+    rel = np.ones((side, side), dtype=np.float32)
+    img[0:16, 0:16] = 0.5     # bin 512
+    img[5, 3] = 0.0           # thread stops at m = 3, n = 5: counted = 3 * 16 + 5
+    h = ob.k_gradation_histogram(img, rel, 1)
+    assert h[512] == (3 * 16 + 5) * 100
+    assert h.sum() == (3 * 16 + 5) * 100
+    # weights: uint(relevant * 100) truncates; bins outside [0, 1024) are dropped
+    img2 = np.zeros((side, side), dtype=np.float32)
+    rel2 = np.zeros((side, side), dtype=np.float32)
+    img2[0:16, 0:16] = 0.25
+    rel2[0:16, 0:16] = 0.999
+    img2[0, 0] = 1.5          # bin 1536 -> dropped
+    img2[1, 0] = -0.0001      # int(-0.1) = 0 -> bin 0
+    h2 = ob.k_gradation_histogram(img2, rel2, 1)
+    assert h2[256] == 254 * 99 and h2[0] == 99 and h2.sum() == 255 * 99
+
+
+def test_gradation_curve_closed_form(ob):
+    h = np.zeros(1024, dtype=np.uint32)
+    h[200:600] = 1000          # count = 10 per bin
+    h[300] = 5000              # count 50 -> but argmax is searched only over [10, meanBin)
+    c = ob.k_gradation_curve_generate(h)
+    counts = h // 100
+    i = np.arange(1024)
+    mean_bin = int((counts[10:] * i[10:]).sum() // counts[10:].sum())
+    arg = 10 + int(np.argmax(counts[10:mean_bin]))
+    assert arg == 300
+    assert c.ta == np.float32(300 / 1024)
+    # t0: walk down from 300 while count >= uint(50 * 0.05) = 2 -> bin 200; minus 0.01
+    np.testing.assert_allclose(c.t0, np.float32(200 / 1024) - np.float32(0.01), rtol=1e-6)
+    assert c.t1 == np.float32(599 / 1024)
+    assert c.pointsCount == 22
+    pts = c.as_array().astype(np.float64)
+    assert tuple(pts[0]) == (0.0, 0.0) and tuple(pts[-1]) == (1.0, 1.0)
+    ta, t0, t1 = 300 / 1024, 200 / 1024 - 0.01, 599 / 1024
+    tf = max(ta - 0.5 / 3, t0)
+    m = 0.5 / (ta - tf) if tf == t0 else 3.0
+    ts = 0.5 / m + ta
+    t = np.arange(10) / 10.0
+
+    def bez(s, mid, e):
+        return ((1 - t) ** 2)[:, None] * np.array(s) + (2 * t * (1 - t))[:, None] * np.array(mid) + (t ** 2)[:, None] * np.array(e)
+    expect = np.concatenate([[[0, 0]], bez((t0, 0), (tf, 0), (ta, .5)), bez((ta, .5), (ts, 1), (t1, 1)), [[1, 1]]])
+    np.testing.assert_allclose(pts, expect, atol=2e-6)
+
+
+def test_gradation_curve_empty_histogram(ob):
+    c = ob.k_gradation_curve_generate(np.zeros(1024, dtype=np.uint32))
+    assert (c.t0, c.ta, c.t1) == (0.0, 0.0, 0.0)   # meanCount / 0 restated as 0
+    assert c.pointsCount == 22
+
+
+def test_gradation_curve_uint32_wrap(ob):
+    # meanCount = sum(count * i) is a 32-bit uint in GLSL and wraps (gradation_curve_generate.comp:63-72)
+    h = np.zeros(1024, dtype=np.uint32)
+    h[1000] = 5_000_000 * 100
+    c = ob.k_gradation_curve_generate(h)
+    wrapped = (5_000_000 * 1000) % (1 << 32)
+    mean_bin = wrapped // 5_000_000
+    assert mean_bin != 1000
+    # argmax is searched over [10, mean_bin): nothing there -> maxPosition 0
+    assert c.ta == 0.0
+
+
+def test_cnr_and_relevant(ob):
+    sd = np.full((8, 8), 0.01, dtype=np.float32)
+    out = ob.k_cnr(sd, 0)          # maxBin = 0 -> reference level clipped to 0.1 / 2048
+    np.testing.assert_allclose(out, 0.01 / (0.1 / 2048) / 256, rtol=1e-6)
+    out = ob.k_cnr(sd, 41)
+    np.testing.assert_allclose(out, 0.01 / (41 / 2048 * 0.1) / 256, rtol=1e-6)
+    # relevant: border 100, ramp (c/6)^5 on [1, 6], 1 on [6, 256] when pixel <= 0.9
+    n = 256
+    norm = np.full((n, n), 0.5, dtype=np.float32)
+    norm[150, 150] = 0.95
+    cnr = np.zeros((32, 32), dtype=np.float32)
+    cnr[:, :] = 10.0 / 256
+    cnr[16, 16] = 3.0 / 256        # covers x, y in [128, 136)
+    cnr[17, 17] = 0.5 / 256
+    cnr[20, 20] = 300.0 / 256
+    rel = ob.k_relevant(norm, cnr)
+    assert rel[:101, :].max() == 0 and rel[:, :101].max() == 0 and rel[n - 100:, :].max() == 0
+    assert rel[101, 101] == 1.0 and rel[n - 101, n - 101] == 1.0
+    np.testing.assert_allclose(rel[130, 130], (3.0 / 6.0) ** 5, rtol=1e-6)
+    assert rel[17 * 8, 17 * 8] == 0.0 and rel[20 * 8, 20 * 8] == 0.0
+    assert rel[150, 150] == 0.0    # pixel > 0.9
+
+
+def test_sdev_border_and_orders(ob):
+    a = np.ones((8, 8), dtype=np.float32)
+    out = ob.k_sdev(a, 0)
+    np.testing.assert_allclose(out[4, 4], 1.0, rtol=1e-6)
+    np.testing.assert_allclose(out[0, 0], np.sqrt(9 / 25), rtol=1e-6)   # OOB taps are 0, divisor stays 25
+    np.testing.assert_allclose(out[0, 4], np.sqrt(15 / 25), rtol=1e-6)
+    rng = _rng(3)
+    b = (rng.random((33, 33), dtype=np.float32) - 0.5) * 0.1
+    np.testing.assert_allclose(ob.k_sdev(b, 0), ob.k_sdev(b, 1), rtol=2e-6, atol=1e-9)
+
+
+# (11) BMP bytes for a 3x3 ramp incl. row padding, and against the reference's own stb writer
+def test_bmp_bytes_3x3(ob, tmp_path):
+    data = np.arange(9, dtype=np.uint8).reshape(3, 3) * 10
+    p = tmp_path / "a.bmp"
+    ob.write_bmp_gray(str(p), data)
+    raw = p.read_bytes()
+    assert len(raw) == 54 + 3 * 12          # 9 bytes of pixels + 3 bytes of padding per row
+    assert raw[:2] == b"BM"
+    assert int.from_bytes(raw[2:6], "little") == 54 + 36
+    assert int.from_bytes(raw[10:14], "little") == 54
+    assert int.from_bytes(raw[14:18], "little") == 40
+    assert int.from_bytes(raw[18:22], "little") == 3 and int.from_bytes(raw[22:26], "little") == 3
+    assert int.from_bytes(raw[26:28], "little") == 1 and int.from_bytes(raw[28:30], "little") == 24
+    assert raw[30:54] == bytes(24)
+    # bottom-up: first stored row is image row 2
+    assert raw[54:66] == bytes([60, 60, 60, 70, 70, 70, 80, 80, 80, 0, 0, 0])
+    assert raw[78:90] == bytes([0, 0, 0, 10, 10, 10, 20, 20, 20, 0, 0, 0])
+
+
+@pytest.mark.parametrize("w,h", [(3, 3), (4, 2), (5, 7), (492, 492), (1, 1)])
+def test_bmp_matches_reference_stb(ob, tmp_path, w, h):
+    if not ob.ref_bmp_available():
+        pytest.skip("oracle/_ref/libref_bmp.so not built (reference tree absent at build time)")
+    data = _rng(w * 100 + h).integers(0, 256, size=(h, w), dtype=np.uint8)
+    a, b = tmp_path / "mine.bmp", tmp_path / "ref.bmp"
+    ob.write_bmp_gray(str(a), data)
+    ob.ref_write_bmp_gray(str(b), data)
+    assert a.read_bytes() == b.read_bytes()
+
+
+def test_raw_reader(ob, tmp_path):
+    n = 16
+    px = _rng(9).integers(0, 65536, size=(n, n), dtype=np.uint16)
+    p = tmp_path / "x.raw"
+    p.write_bytes(bytes(range(256)) + px.astype("<u2").tobytes())
+    got = ob.read_raw(str(p), n)
+    assert np.array_equal(got, px)
+    p.write_bytes(bytes(255) + px.astype("<u2").tobytes())      # wrong size must be rejected (main.cpp:57-60)
+    assert ob.read_raw(str(p), n) is None
