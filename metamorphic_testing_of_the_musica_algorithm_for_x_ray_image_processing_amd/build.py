@@ -1,0 +1,74 @@
+"""Builds libmusica_hip.so and musica-standalone in-tree with hipcc for gfx950.
+
+    python -m metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.build
+
+-ffp-contract=off keeps every f32 multiply and add separately rounded (the parity contract with
+oracle/musica_oracle.c); IEEE division and sqrt are hipcc's default for HIP.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmusica_hip.so")
+CLI = os.path.join(HERE, "musica-standalone")
+HIP_SOURCES = ["kernels_pyramid.hip", "kernels_analysis.hip", "kernels_gradation.hip", "kernels_clahe.hip", "musica_ctx.hip"]
+CPP_SOURCES = ["musica_io.cpp"]
+HEADERS = ["musica_device.h", "kernels_common.h", "launchers.h", os.path.join("..", "..", "include", "musica.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    objs = []
+    procs = []
+    for src in HIP_SOURCES + CPP_SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [sp] + headers):
+            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write("hipcc failed on %s:\n%s\n" % (src, out))
+        elif verbose and out.strip():
+            print(out)
+    if failed:
+        raise RuntimeError("building libmusica_hip.so failed")
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        subprocess.run(cmd, check=True)
+    cli_src = os.path.join(CSRC, "musica_standalone.cpp")
+    if force or _stale(CLI, [cli_src, LIB]):
+        cmd = [hipcc, "-O2", "-std=c++17", cli_src, "-o", CLI, "-L" + HERE, "-lmusica_hip", "-Wl,-rpath,$ORIGIN"]
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB)

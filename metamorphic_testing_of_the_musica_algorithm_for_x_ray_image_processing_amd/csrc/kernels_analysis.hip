@@ -1,0 +1,450 @@
+// kernels_analysis.hip — normalisation and image-analysis kernels of the MUSICA path (gfx950).
+//
+//   k_clear         : vkCmdClearColorImage of the histograms (src/vk_processing.cpp:2153-2162) + reduction seeds
+//   k_minmax_u16    : img_sqrt.comp + img_max_reduce.comp chain + min_reduce.comp chain   (K1 + K2 + K3)
+//   k_normalize     : img_sqrt.comp + img_normalize.comp                                    (K1 + K4)
+//   k_sdev_hist     : img_sdev.comp + noise_hist.comp fused                                 (K10 + K11)
+//   k_noise_curves  : img_histogram_max.comp + contrast_curve_generate.comp                 (K12 + K13)
+//   k_cnr           : img_cnr.comp                                                          (K15)
+//   k_sqrt          : img_sqrt.comp alone (debug image)
+#include <algorithm>
+#include "kernels_common.h"
+#include "launchers.h"
+
+namespace musica {
+
+// ---- clears ---------------------------------------------------------------------------
+// minmax[b] = {min = 0xFFFFFFFF, max = 0}; noise_hist[b][4][2048] = 0; grad_hist[b][1024] = 0; clahe hist = 0.
+__global__ void k_clear(uint32_t* __restrict__ minmax, uint32_t* __restrict__ noise_hist, uint32_t* __restrict__ grad_hist,
+                        uint32_t* __restrict__ clahe_hist, int batch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nh = batch * 4 * MUSICA_NOISE_BINS, gh = batch * MUSICA_GRAD_BINS;
+    const int ch = clahe_hist ? batch * MUSICA_CLAHE_TILES * MUSICA_CLAHE_TILES * MUSICA_CLAHE_BINS : 0;
+    if (minmax && i < batch) { minmax[2 * i] = 0xFFFFFFFFu; minmax[2 * i + 1] = 0u; }
+    if (noise_hist && i < nh) noise_hist[i] = 0u;
+    if (grad_hist && i < gh) grad_hist[i] = 0u;
+    if (i < ch) clahe_hist[i] = 0u;
+}
+
+// ---- K1 + K2 + K3 ---------------------------------------------------------------------
+// sqrt is monotone and the chains' float(uint(.)) truncation (img_max_reduce.comp:53, min_reduce.comp:30)
+// is monotone too, so the chain results are functions of the integer extrema of the raw pixels:
+//   max chain  -> floor(sqrt(max u16))            (every link floors; zeros from partial blocks never win)
+//   min chain  -> floor(sqrt(min u16)) when every link has only full 8x8 blocks (N a power of 8),
+//                 0 otherwise (a partial block reads out-of-image zeros, min_reduce.comp:22-27 + Q1).
+// So this kernel reduces the uint16 pixels exactly (wavefront DPP reduction, one atomic pair per block).
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_minmax_u16(const uint16_t* __restrict__ px, size_t count, uint32_t* __restrict__ minmax) {
+    const uint16_t* p = px + (size_t)blockIdx.z * count;
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    const size_t nvec = (((uintptr_t)p & 15u) == 0) ? count / 8 : 0;  // 8 pixels per 16-byte load
+    const uint4* pv = reinterpret_cast<const uint4*>(p);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 q = pv[i];
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t lo = w[k] & 0xFFFFu, hi = w[k] >> 16;
+            mn = min(mn, min(lo, hi));
+            mx = max(mx, max(lo, hi));
+        }
+    }
+    for (size_t i = nvec * 8 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t v = p[i];
+        mn = min(mn, v);
+        mx = max(mx, v);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    __shared__ uint32_t smn[4], smx[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { smn[wv] = mn; smx[wv] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = min(min(smn[0], smn[1]), min(smn[2], smn[3]));
+        mx = max(max(smx[0], smx[1]), max(smx[2], smx[3]));
+        atomicMin(&minmax[2 * blockIdx.z], mn);
+        atomicMax(&minmax[2 * blockIdx.z + 1], mx);
+    }
+}
+
+// The two scalars img_normalize.comp:17-18 reads from the 1x1 ends of the chains.
+__device__ __forceinline__ void chain_scalars(const uint32_t* __restrict__ minmax, int img, int min_chain_exact, float& minv, float& maxv) {
+    const uint32_t mnu = minmax[2 * img], mxu = minmax[2 * img + 1];
+    maxv = (float)f2u(sqrtf((float)mxu));
+    minv = min_chain_exact ? (float)f2u(sqrtf((float)mnu)) : 0.0f;
+}
+
+// ---- K1 + K4 --------------------------------------------------------------------------
+// out = (sqrt(float(px)) - min) / (max - min), unclamped (img_normalize.comp:24-27).
+// Vector path: 8 pixels per thread when N % 8 == 0 (dense u16 rows and pitched f32 rows both 16-byte aligned).
+__global__ __launch_bounds__(256) void k_normalize(const uint16_t* __restrict__ px, float* __restrict__ out, int N, int pitch,
+                                                   size_t plane, const uint32_t* __restrict__ minmax, int min_chain_exact) {
+    const int img = blockIdx.z;
+    float minv, maxv;
+    chain_scalars(minmax, img, min_chain_exact, minv, maxv);
+    const float den = maxv - minv;
+    const uint16_t* p = px + (size_t)img * N * N;
+    float* o = out + (size_t)img * plane;
+    if ((N & 7) == 0 && ((uintptr_t)p & 15u) == 0) {
+        const int vec_per_row = N >> 3;
+        const size_t total = (size_t)vec_per_row * N;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const int y = (int)(i / vec_per_row), xv = (int)(i % vec_per_row);
+            const uint4 q = *reinterpret_cast<const uint4*>(p + (size_t)y * N + xv * 8);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            float r[8];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                r[2 * k] = (sqrtf((float)(w[k] & 0xFFFFu)) - minv) / den;
+                r[2 * k + 1] = (sqrtf((float)(w[k] >> 16)) - minv) / den;
+            }
+            float* d = o + (size_t)y * pitch + xv * 8;
+            *reinterpret_cast<float4*>(d) = make_float4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<float4*>(d + 4) = make_float4(r[4], r[5], r[6], r[7]);
+        }
+    } else {
+        const size_t total = (size_t)N * N;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const int y = (int)(i / N), x = (int)(i % N);
+            o[(size_t)y * pitch + x] = (sqrtf((float)p[i]) - minv) / den;
+        }
+    }
+}
+
+__global__ void k_sqrt(const uint16_t* __restrict__ px, float* __restrict__ out, int N, int pitch, size_t plane) {
+    const uint16_t* p = px + (size_t)blockIdx.z * N * N;
+    float* o = out + (size_t)blockIdx.z * plane;
+    const size_t total = (size_t)N * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / N), x = (int)(i % N);
+        o[(size_t)y * pitch + x] = sqrtf((float)p[i]);
+    }
+}
+
+// ---- K10 + K11 ------------------------------------------------------------------------
+// sdev(x, y) = sqrt( sum_{5x5} band^2 / 25 ), taps outside the image are 0 and the divisor stays 25
+// (img_sdev.comp:14-30). ORDER_FAST: vertical chain of squares, then horizontal chain.
+// The noise histogram (noise_hist.comp) is accumulated on the fly: the reference's thread (gx, gy)
+// walks its 16x16 area column by column (m = x outer, n = y inner) and `break`s out of a column at
+// the first pixel that is 0, > 0.1 or lands in bin 0 — i.e. each (column, 16-row run) is an
+// independent early-exit scan. A lane of this kernel owns 8 columns and marches down rows, so it
+// sees every run in exactly that order: one `alive` bit per owned column, re-armed every 16 rows.
+// Bins are privatised in LDS (8 KiB per block) and flushed with one global atomic per non-empty bin.
+struct SRow {
+    float q[8];    // squares of columns c .. c+7
+    float l0, l1;  // squares of columns c-2, c-1   (lane 0 of a strip that is not the first)
+    float h0, h1;  // squares of columns c+8, c+9   (lane 63)
+};
+
+__device__ __forceinline__ void load_srow(SRow& r, const float* __restrict__ base, int pitch, int S, int row, int c, bool lane0,
+                                          bool lane63) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.q[j] = 0.f;
+    r.l0 = r.l1 = r.h0 = r.h1 = 0.f;
+    if (row < 0 || row >= S) return;  // Q1: out-of-image rows are zeros
+    const float* p = base + (size_t)row * pitch;
+    const float4 a = load4_guard(p, c, S), b = load4_guard(p, c + 4, S);
+    r.q[0] = a.x * a.x; r.q[1] = a.y * a.y; r.q[2] = a.z * a.z; r.q[3] = a.w * a.w;
+    r.q[4] = b.x * b.x; r.q[5] = b.y * b.y; r.q[6] = b.z * b.z; r.q[7] = b.w * b.w;
+    if (lane0 && c >= 2) {
+        const float u = p[c - 2], v = p[c - 1];
+        r.l0 = u * u; r.l1 = v * v;
+    }
+    if (lane63) {
+        if (c + 8 < S) { const float u = p[c + 8]; r.h0 = u * u; }
+        if (c + 9 < S) { const float u = p[c + 9]; r.h1 = u * u; }
+    }
+}
+
+__device__ __forceinline__ float sum5(float a, float b, float c, float d, float e) {
+    float acc = a;
+    acc = acc + b;
+    acc = acc + c;
+    acc = acc + d;
+    acc = acc + e;
+    return acc;
+}
+
+// rows_per_wave must be a multiple of 16 (histogram runs start at y % 16 == 0).
+// cov = (imageSize / 512) * 512: the part of the grid the reference's dispatch covers (src/vk_processing.cpp:2293-2295).
+__global__ __launch_bounds__(kBlockThreads) void k_sdev_hist(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
+                                                             size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov,
+                                                             int rows_per_wave) {
+    __shared__ uint32_t lh[MUSICA_NOISE_BINS];
+    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS; i += blockDim.x) lh[i] = 0u;
+    __syncthreads();
+    const int img = blockIdx.z;
+    band += (size_t)img * plane;
+    sdev += (size_t)img * plane;
+    const int lane = threadIdx.x & 63;
+    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int y0 = seg * rows_per_wave;
+    const int c = blockIdx.x * kStripCols + lane * kLaneCols;
+    const bool lane0 = lane == 0, lane63 = lane == 63;
+    if (y0 < S) {
+        const int y1 = min(y0 + rows_per_wave, S);
+        SRow r0, r1, r2, r3, r4, nx;
+        load_srow(r0, band, pitch, S, y0 - 2, c, lane0, lane63);
+        load_srow(r1, band, pitch, S, y0 - 1, c, lane0, lane63);
+        load_srow(r2, band, pitch, S, y0, c, lane0, lane63);
+        load_srow(r3, band, pitch, S, y0 + 1, c, lane0, lane63);
+        load_srow(r4, band, pitch, S, y0 + 2, c, lane0, lane63);
+        uint32_t alive = 0;
+        for (int y = y0; y < y1; y++) {
+            load_srow(nx, band, pitch, S, y + 3, c, lane0, lane63);
+            float q[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) q[j] = sum5(r0.q[j], r1.q[j], r2.q[j], r3.q[j], r4.q[j]);
+            const float ql0 = sum5(r0.l0, r1.l0, r2.l0, r3.l0, r4.l0), ql1 = sum5(r0.l1, r1.l1, r2.l1, r3.l1, r4.l1);
+            const float qh0 = sum5(r0.h0, r1.h0, r2.h0, r3.h0, r4.h0), qh1 = sum5(r0.h1, r1.h1, r2.h1, r3.h1, r4.h1);
+            float a6 = from_left_lane(q[6]), a7 = from_left_lane(q[7]);
+            float b0 = from_right_lane(q[0]), b1 = from_right_lane(q[1]);
+            if (lane0) { a6 = ql0; a7 = ql1; }    // zeros at the image's left edge (loads skipped)
+            if (lane63) { b0 = qh0; b1 = qh1; }   // zeros beyond the right edge
+            // lanes right of the image hold q == 0, so the last in-image lane reads zeros from its neighbour
+            float s[8];
+            s[0] = sum5(a6, a7, q[0], q[1], q[2]);
+            s[1] = sum5(a7, q[0], q[1], q[2], q[3]);
+            s[2] = sum5(q[0], q[1], q[2], q[3], q[4]);
+            s[3] = sum5(q[1], q[2], q[3], q[4], q[5]);
+            s[4] = sum5(q[2], q[3], q[4], q[5], q[6]);
+            s[5] = sum5(q[3], q[4], q[5], q[6], q[7]);
+            s[6] = sum5(q[4], q[5], q[6], q[7], b0);
+            s[7] = sum5(q[5], q[6], q[7], b0, b1);
+#pragma unroll
+            for (int j = 0; j < 8; j++) s[j] = sqrtf(s[j] / 25.0f);  // img_sdev.comp:30
+            if (c < S) {
+                float* d = sdev + (size_t)y * pitch + c;
+                if (c + 8 <= S) {
+                    *reinterpret_cast<float4*>(d) = make_float4(s[0], s[1], s[2], s[3]);
+                    *reinterpret_cast<float4*>(d + 4) = make_float4(s[4], s[5], s[6], s[7]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (c + j < S) d[j] = s[j];
+                }
+            }
+            // noise_hist.comp:20-47
+            if ((y & (kHistArea - 1)) == 0) alive = 0xFFu;
+            if (y < cov) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (!(alive & (1u << j))) continue;
+                    const int x = c + j;
+                    const float cur = (x < S && x < cov) ? s[j] : 0.0f;
+                    bool brk = (cur == 0.0f);                                   // :29
+                    int bin = 0;
+                    if (!brk) {
+                        const float adj = cur / kMaxNoiseValue;                   // :31
+                        if (adj > 1.0f) brk = true;                               // :33
+                        else {
+                            bin = (int)(adj * (float)MUSICA_NOISE_BINS + 0.5f);   // :35
+                            if (bin == 0) brk = true;                             // :39
+                        }
+                    }
+                    if (brk) alive &= ~(1u << j);
+                    else if (bin > 0 && bin < MUSICA_NOISE_BINS) atomicAdd(&lh[bin], 1u);  // :45 (bin 2048 is dropped, Q1)
+                }
+            }
+            r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = nx;
+        }
+    }
+    __syncthreads();
+    uint32_t* gh = hist + (size_t)img * hist_stride;
+    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS; i += blockDim.x) {
+        const uint32_t v = lh[i];
+        if (v) atomicAdd(&gh[i], v);
+    }
+}
+
+// histogram only (kernel-level parity tests feed a foreign sdev image): same scan, no stencil.
+__global__ __launch_bounds__(kBlockThreads) void k_noise_hist_only(const float* __restrict__ sdev, int S, int pitch, size_t plane,
+                                                                   uint32_t* __restrict__ hist, size_t hist_stride, int cov) {
+    __shared__ uint32_t lh[MUSICA_NOISE_BINS];
+    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS; i += blockDim.x) lh[i] = 0u;
+    __syncthreads();
+    const int img = blockIdx.z;
+    sdev += (size_t)img * plane;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;   // one column per thread
+    const int y0 = blockIdx.y * kHistArea;
+    if (x < S && x < cov && y0 < cov) {
+        for (int n = 0; n < kHistArea; n++) {
+            const int y = y0 + n;
+            const float cur = (y < S && y < cov) ? sdev[(size_t)y * pitch + x] : 0.0f;
+            if (cur == 0.0f) break;
+            const float adj = cur / kMaxNoiseValue;
+            if (adj > 1.0f) break;
+            const int bin = (int)(adj * (float)MUSICA_NOISE_BINS + 0.5f);
+            if (bin == 0) break;
+            if (bin < MUSICA_NOISE_BINS) atomicAdd(&lh[bin], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* gh = hist + (size_t)img * hist_stride;
+    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS; i += blockDim.x) {
+        const uint32_t v = lh[i];
+        if (v) atomicAdd(&gh[i], v);
+    }
+}
+
+// ---- K12 + K13 ------------------------------------------------------------------------
+// Block-wide argmax with the lowest index winning ties (img_histogram_max.comp:20-29: strict `>`
+// while scanning upwards; an all-zero histogram yields (0, 0)).
+__device__ __forceinline__ unsigned long long argmax_key(uint32_t value, uint32_t index) {
+    return value ? (((unsigned long long)value << 32) | (unsigned long long)(0xFFFFFFFFu - index)) : 0ull;
+}
+__device__ __forceinline__ unsigned long long block_max_u64(unsigned long long k, unsigned long long* scratch /*[16]*/) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long other = __shfl_xor(k, o);
+        k = other > k ? other : k;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) scratch[wv] = k;
+    __syncthreads();
+    unsigned long long r = 0ull;
+    for (int i = 0; i < nw; i++) r = scratch[i] > r ? scratch[i] : r;
+    __syncthreads();
+    return r;
+}
+
+// grid (levels, batch), 256 threads. Levels 0..3 take the argmax of their noise histogram; every
+// level then builds its contrast curve (src/vk_processing.cpp:2284-2320).
+__global__ __launch_bounds__(256) void k_noise_curves(const uint32_t* __restrict__ hist, size_t hist_stride,
+                                                      musica_hist_max_point* __restrict__ maxpts, DevCurve* __restrict__ curves,
+                                                      const musica_contrast_params* __restrict__ cparams, int levels) {
+    __shared__ unsigned long long scratch[16];
+    const int level = blockIdx.x, img = blockIdx.y;
+    musica_hist_max_point mp;
+    mp.maxValue = 0; mp.maxBin = 0;
+    if (level <= MUSICA_CNR_LEVEL) {
+        const uint32_t* h = hist + (size_t)img * hist_stride + (size_t)level * MUSICA_NOISE_BINS;
+        unsigned long long k = 0ull;
+        for (int i = threadIdx.x; i < MUSICA_NOISE_BINS; i += blockDim.x) {
+            const unsigned long long ki = argmax_key(h[i], (uint32_t)i);
+            k = ki > k ? ki : k;
+        }
+        k = block_max_u64(k, scratch);
+        if (k) { mp.maxValue = (uint32_t)(k >> 32); mp.maxBin = 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull); }
+    }
+    if (threadIdx.x != 0) return;
+    maxpts[(size_t)img * levels + level] = mp;
+    DevCurve* c = curves + (size_t)img * levels + level;
+    const float low = cparams[level].lowContrastFactor, high = cparams[level].highContrastFactor;
+    uint32_t n = 0;
+    if (low == 1.0f) {                                                                      // contrast_curve_generate.comp:59
+        c->x[0] = 0.0f; c->y[0] = high;                                                     // :68
+        c->x[1] = 1.0f; c->y[1] = high;                                                     // :69
+        n = 2;
+    } else {
+        const float p = (float)mp.maxBin * (1.0f / (float)MUSICA_NOISE_BINS) * kMaxNoiseValue;  // :71
+        generate_curve(c, n, 0.0f, 1.0f, p * 4.0f / 5.0f, low, p, low, 11);                                   // :72-76
+        generate_curve(c, n, p, low, p * 6.0f / 5.0f, low, p * 7.0f / 5.0f, low * 4.0f / 5.0f, 11);           // :77-81
+        generate_curve(c, n, p * 7.0f / 5.0f, low * 4.0f / 5.0f, p * 2.0f, 1.0f, 1.0f, 1.0f, 11);             // :82-86
+    }
+    c->count = n;
+    c->t0 = c->ta = c->t1 = 0.0f;
+    curve_finish(c);
+}
+
+// ---- K15 ------------------------------------------------------------------------------
+__global__ void k_cnr(const float* __restrict__ sdev, float* __restrict__ cnr, int S, int pitch, size_t plane,
+                      const musica_hist_max_point* __restrict__ maxpts, int levels) {
+    const int img = blockIdx.z;
+    const musica_hist_max_point mp = maxpts[(size_t)img * levels + MUSICA_CNR_LEVEL];
+    float ref = (float)mp.maxBin * (1.0f / (float)MUSICA_NOISE_BINS) * kMaxNoiseValue;          // img_cnr.comp:22
+    if (ref == 0.0f) ref = (1.0f / (float)MUSICA_NOISE_BINS) * kMaxNoiseValue;                  // :25
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= S || y >= S) return;
+    const size_t o = (size_t)img * plane + (size_t)y * pitch + x;
+    const float v = sdev[o] / ref;                                                              // :31
+    cnr[o] = v / kMaxCnrValue;                                                                  // :43
+}
+
+// Deterministic per-image sum of the cnr image in double (for musica_stats.mean_cnr):
+// one block per image, fixed partition, fixed tree.
+__global__ __launch_bounds__(256) void k_sum_image(const float* __restrict__ img, int S, int pitch, size_t plane, double* __restrict__ out) {
+    __shared__ double part[256];
+    const float* p = img + (size_t)blockIdx.x * plane;
+    double acc = 0.0;
+    for (int y = 0; y < S; y++)
+        for (int x = threadIdx.x; x < S; x += blockDim.x) acc += (double)p[(size_t)y * pitch + x];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+}
+
+// ======================================================================================
+// host-side launchers
+// ======================================================================================
+
+void launch_clear(hipStream_t st, uint32_t* minmax, uint32_t* noise_hist, uint32_t* grad_hist, uint32_t* clahe_hist, int batch) {
+    int n = batch * 4 * MUSICA_NOISE_BINS;
+    if (clahe_hist) n = max(n, batch * MUSICA_CLAHE_TILES * MUSICA_CLAHE_TILES * MUSICA_CLAHE_BINS);
+    hipLaunchKernelGGL(k_clear, dim3((n + 255) / 256), dim3(256), 0, st, minmax, noise_hist, grad_hist, clahe_hist, batch);
+}
+
+void launch_minmax(hipStream_t st, const uint16_t* px, int N, uint32_t* minmax, int batch) {
+    const size_t count = (size_t)N * N;
+    int blocks = (int)std::min<size_t>((count / 8 + 255) / 256, (size_t)1024);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_minmax_u16, dim3(blocks, 1, batch), dim3(256), 0, st, px, count, minmax);
+}
+
+void launch_normalize(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, const uint32_t* minmax,
+                      int min_chain_exact, int batch) {
+    const size_t items = (l0.S & 7) == 0 ? (size_t)l0.S * l0.S / 8 : (size_t)l0.S * l0.S;
+    int blocks = (int)std::min<size_t>((items + 255) / 256, (size_t)4096);
+    hipLaunchKernelGGL(k_normalize, dim3(blocks, 1, batch), dim3(256), 0, st, px, out, l0.S, l0.pitch, l0.plane, minmax,
+                       min_chain_exact);
+}
+
+void launch_sqrt(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, int batch) {
+    hipLaunchKernelGGL(k_sqrt, dim3(1024, 1, batch), dim3(256), 0, st, px, out, l0.S, l0.pitch, l0.plane);
+}
+
+void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov,
+                      int batch, int rows_per_wave) {
+    const int strips = (l.S + kStripCols - 1) / kStripCols;
+    const int segs = (l.S + rows_per_wave - 1) / rows_per_wave;
+    hipLaunchKernelGGL(k_sdev_hist, dim3(strips, (segs + kWavesPerBlock - 1) / kWavesPerBlock, batch), dim3(kBlockThreads), 0, st, band,
+                       sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
+}
+
+void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch) {
+    hipLaunchKernelGGL(k_noise_hist_only, dim3((l.S + kBlockThreads - 1) / kBlockThreads, (l.S + kHistArea - 1) / kHistArea, batch),
+                       dim3(kBlockThreads), 0, st, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov);
+}
+
+void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves,
+                         const musica_contrast_params* cparams, int levels, int batch) {
+    hipLaunchKernelGGL(k_noise_curves, dim3(levels, batch), dim3(256), 0, st, hist, hist_stride, maxpts, curves, cparams, levels);
+}
+
+void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& l3, const musica_hist_max_point* maxpts, int levels,
+                int batch) {
+    hipLaunchKernelGGL(k_cnr, dim3((l3.S + 31) / 32, (l3.S + 7) / 8, batch), dim3(32, 8), 0, st, sdev, cnr, l3.S, l3.pitch, l3.plane,
+                       maxpts, levels);
+}
+
+void launch_sum_image(hipStream_t st, const float* img, const LevelDesc& l, double* out, int batch) {
+    hipLaunchKernelGGL(k_sum_image, dim3(batch), dim3(256), 0, st, img, l.S, l.pitch, l.plane, out);
+}
+
+}  // namespace musica

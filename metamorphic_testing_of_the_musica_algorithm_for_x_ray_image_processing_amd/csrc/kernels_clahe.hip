@@ -1,0 +1,141 @@
+// kernels_clahe.hip — the CLAHE gradation alternative (clahe_histogram.comp, clahe_grad_curve.comp,
+// clahe_grad_curve_apply.comp; K22-K24). The reference keeps it behind `#ifdef ENABLE_CLAHE`
+// (include/vk_processing.h:13, commented out) and its host wiring does not compile, so these
+// kernels restate the shader text only (oracle: musica_oracle_k_clahe_*). Decisions shared with the
+// oracle: relevantImage is read as the f32 it really is; float -> uint of a negative tile
+// coordinate saturates to 0; points[256] (one past the per-tile curve) reads as (0, 0); the
+// histogram image is cleared at the start of every execute.
+#include "kernels_common.h"
+#include "launchers.h"
+
+namespace musica {
+
+constexpr int kT = MUSICA_CLAHE_TILES;
+constexpr int kB = MUSICA_CLAHE_BINS;
+
+// K22 clahe_histogram.comp:13-45 — hist[tx][ty][bin] += 1 where relevant == 1.0
+__global__ __launch_bounds__(256) void k_clahe_hist(const float* __restrict__ img, const float* __restrict__ relevant, int N, int pitch,
+                                                    size_t plane, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[kT * kT * kB];
+    for (int i = threadIdx.x; i < kT * kT * kB; i += blockDim.x) lh[i] = 0u;
+    __syncthreads();
+    img += (size_t)blockIdx.z * plane;
+    relevant += (size_t)blockIdx.z * plane;
+    const size_t total = (size_t)N * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / N), x = (int)(i % N);
+        const float cur = img[(size_t)y * pitch + x];
+        if (cur != cur) continue;
+        const float scaled = cur * (float)(kB - 1) + 0.5f;                       // :20
+        if (!(scaled > -2147483648.0f && scaled < 2147483648.0f)) continue;
+        const int bin = (int)scaled;
+        const uint32_t tx = f2u((float)x / (float)N * (float)kT);               // :34
+        const uint32_t ty = f2u((float)y / (float)N * (float)kT);               // :35
+        if (relevant[(size_t)y * pitch + x] == 1.0f && bin >= 0 && bin < kB && tx < (uint32_t)kT && ty < (uint32_t)kT)
+            atomicAdd(&lh[(tx * kT + ty) * kB + bin], 1u);                       // :39-44
+    }
+    __syncthreads();
+    uint32_t* gh = hist + (size_t)blockIdx.z * kT * kT * kB;
+    for (int i = threadIdx.x; i < kT * kT * kB; i += blockDim.x) {
+        const uint32_t v = lh[i];
+        if (v) atomicAdd(&gh[i], v);
+    }
+}
+
+// K23 clahe_grad_curve.comp:21-100 — one thread per tile (local_size 4x4, one workgroup).
+__global__ void k_clahe_curve(const uint32_t* __restrict__ hist, musica_point* __restrict__ points) {
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const uint32_t* h = hist + ((size_t)blockIdx.x * kT * kT + (size_t)tx * kT + ty) * kB;
+    musica_point* pts = points + ((size_t)blockIdx.x * kT * kT + (size_t)tx * kT + ty) * kB;
+    uint32_t count = 0;
+    for (int i = 0; i < kB; i++) count += h[i];                                  // :31-43
+    const float clipLimit = 1.0f / 32.0f;                                        // :60
+    float clipCount = 0.0f;
+    for (int i = 0; i < kB; i++) {                                               // :47-57, :63-69
+        const float ny = (float)h[i] / (float)count;
+        if (ny > clipLimit) clipCount += ny - clipLimit;
+    }
+    const float clipAdd = clipCount / (float)kB;                                 // :76
+    float curr = 0.0f;
+    for (int i = 0; i < kB; i++) {                                               // :78-93
+        float ny = (float)h[i] / (float)count;
+        if (ny > clipLimit) ny = clipLimit;
+        ny += clipAdd;
+        curr += ny;
+        float posX = (float)i * (1.0f / (float)kB);
+        if (i == kB - 1) posX = 1.0f;
+        pts[i].x = posX;
+        pts[i].y = curr;
+    }
+}
+
+// getY() of clahe_grad_curve_apply.comp:27-36 on one tile's 256 points. x[i] = i/256 (x[255] = 1) is
+// strictly increasing, so the first match is i = j - 1 with j = #{x[i] < s} (same argument as curve_eval).
+__device__ __forceinline__ float clahe_x(int i) { return i == kB - 1 ? 1.0f : (float)i * (1.0f / (float)kB); }
+__device__ __forceinline__ float clahe_get_y(const musica_point* __restrict__ pts, float s) {
+    int j = 0;
+#pragma unroll
+    for (int step = 256; step >= 1; step >>= 1) {
+        const int probe = j + step;
+        if (probe <= kB && clahe_x(probe - 1) < s) j = probe;
+    }
+    if (j == 0) return (s == 0.0f) ? pts[0].y : 0.0f;
+    if (j >= kB) return 0.0f;
+    const float y0 = pts[j - 1].y, y1 = pts[j].y, x0 = clahe_x(j - 1), x1 = clahe_x(j);
+    const float m = (y1 - y0) / (x1 - x0);
+    return m * (s - x0) + y0;
+}
+
+__device__ __forceinline__ float signf_(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+// K24 clahe_grad_curve_apply.comp:38-161
+__global__ void k_clahe_apply(const float* __restrict__ in, float* __restrict__ out, int N, int pitch, size_t plane,
+                              const musica_point* __restrict__ points) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= N || y >= N) return;
+    const musica_point* P = points + (size_t)blockIdx.z * kT * kT * kB;
+    const size_t o = (size_t)blockIdx.z * plane + (size_t)y * pitch + x;
+    const float pixel = in[o];
+    const uint32_t G = (uint32_t)N / (uint32_t)kT;                               // :43
+    const float px = (float)x / (float)G, py = (float)y / (float)G;              // :45-48
+    const float bx = (float)f2u(px) + 0.5f, by = (float)f2u(py) + 0.5f;          // :50-53
+    const float dx = px - bx, dy = py - by;                                      // :55-58
+    float combined = 0.0f;
+    if (dx == 0.0f && dy == 0.0f) {
+        const uint32_t tx = f2u(floorf(bx)), ty = f2u(floorf(by));               // :63
+        if (tx < (uint32_t)kT && ty < (uint32_t)kT) combined = clahe_get_y(P + ((size_t)tx * kT + ty) * kB, pixel);
+    } else {
+        const bool usex = dx != 0.0f, usey = dy != 0.0f;
+        float cx[4], cy[4];
+        int cnt;
+        cx[0] = bx; cy[0] = by;
+        if (usex && usey) {
+            cnt = 4;
+            cx[1] = bx + signf_(dx); cy[1] = by;
+            cx[2] = bx; cy[2] = by + signf_(dy);
+            cx[3] = bx + signf_(dx); cy[3] = by + signf_(dy);
+        } else if (usey) { cnt = 2; cx[1] = bx; cy[1] = by + signf_(dy); }
+        else { cnt = 2; cx[1] = bx + signf_(dx); cy[1] = by; }
+        for (int i = 0; i < cnt; i++) {
+            const float tdx = cx[i] - px, tdy = cy[i] - py;
+            uint32_t tx = f2u(floorf(cx[i])), ty = f2u(floorf(cy[i]));
+            if (tx > (uint32_t)kT - 1) tx = kT - 1;                              // :78-79
+            if (ty > (uint32_t)kT - 1) ty = kT - 1;
+            const float g = clahe_get_y(P + ((size_t)tx * kT + ty) * kB, pixel);
+            if (usex && usey) combined += (1.0f - fabsf(tdx)) * (1.0f - fabsf(tdy)) * g;   // :138-146
+            else if (usey) combined += (1.0f - fabsf(tdy)) * g;                  // :81-88
+            else combined += (1.0f - fabsf(tdx)) * g;                            // :107-114
+        }
+    }
+    out[o] = combined;
+}
+
+void launch_clahe(hipStream_t st, const float* img, const float* relevant, float* out, const LevelDesc& l0, uint32_t* hist, musica_point* pts,
+                  int batch) {
+    hipLaunchKernelGGL(k_clahe_hist, dim3(256, 1, batch), dim3(256), 0, st, img, relevant, l0.S, l0.pitch, l0.plane, hist);
+    hipLaunchKernelGGL(k_clahe_curve, dim3(batch), dim3(kT, kT), 0, st, hist, pts);
+    hipLaunchKernelGGL(k_clahe_apply, dim3((l0.S + 31) / 32, (l0.S + 7) / 8, batch), dim3(32, 8), 0, st, img, out, l0.S, l0.pitch, l0.plane, pts);
+}
+
+}  // namespace musica

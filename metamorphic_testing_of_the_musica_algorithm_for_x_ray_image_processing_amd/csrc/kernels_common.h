@@ -1,0 +1,165 @@
+// kernels_common.h — device helpers shared by the HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+
+#include "musica_device.h"
+
+namespace musica {
+
+// ---- cross-lane moves on the 64-wide wavefront (DPP wave shifts, no LDS) ----
+// wave_shr:1 — lane i receives lane i-1 (lane 0 receives 0); wave_shl:1 — lane i receives lane i+1.
+__device__ __forceinline__ float from_left_lane(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float from_right_lane(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+
+// ---- arithmetic in the oracle's MUSICA_ORDER_FAST order ----
+// ((((w0*a + w1*b) + w2*c) + w3*d) + w4*e), products and sums rounded separately.
+__device__ __forceinline__ float chain5(float a, float b, float c, float d, float e) {
+    float acc = W0 * a;
+    acc = acc + W1 * b;
+    acc = acc + W2 * c;
+    acc = acc + W3 * d;
+    acc = acc + W4 * e;
+    return acc;
+}
+// zero-inserted grid, even phase: taps 0, 2, 4 of the 5-tap kernel (the zero taps add +0 exactly).
+__device__ __forceinline__ float chain_even(float a, float b, float c) {
+    float acc = W0 * a;
+    acc = acc + W2 * b;
+    acc = acc + W4 * c;
+    return acc;
+}
+// zero-inserted grid, odd phase: taps 1, 3.
+__device__ __forceinline__ float chain_odd(float a, float b) {
+    float acc = W1 * a;
+    acc = acc + W3 * b;
+    return acc;
+}
+
+// mirror() of img_smooth.comp:10-16 (reflect-101; the clamp there is a no-op).
+__device__ __forceinline__ int mirror_idx(int n, int hi) {
+    int v = n;
+    if (v > hi) v = hi - (v - hi);
+    else if (v < 0) v = -v;
+    return v;
+}
+
+// float -> uint as the GPU's v_cvt_u32_f32 does it: truncate, negative / NaN -> 0, saturate.
+__device__ __forceinline__ uint32_t f2u(float v) {
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+
+// 16-byte load of 4 consecutive floats of a row; columns >= valid_cols come back as 0.
+// `row` must be 16-byte aligned at column x (x % 4 == 0) and x < pitch.
+__device__ __forceinline__ float4 load4_guard(const float* __restrict__ row, int x, int valid_cols) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x < valid_cols) {
+        v = *reinterpret_cast<const float4*>(row + x);
+        if (x + 1 >= valid_cols) v.y = 0.f;
+        if (x + 2 >= valid_cols) v.z = 0.f;
+        if (x + 3 >= valid_cols) v.w = 0.f;
+    }
+    return v;
+}
+
+// ---- polyline evaluation: getY() of contrast_curve_apply.comp:27-36 ----
+// LDS copy of a DevCurve.
+struct CurveLds {
+    float x[kCurveCap];
+    float y[kCurveCap];
+    float m[kCurveCap];
+    uint32_t count;
+    uint32_t monotone;
+};
+
+__device__ __forceinline__ void curve_to_lds(CurveLds& dst, const DevCurve* __restrict__ src) {
+    for (int i = threadIdx.x; i < kCurveCap; i += blockDim.x) {
+        dst.x[i] = src->x[i];
+        dst.y[i] = src->y[i];
+        dst.m[i] = src->m[i];
+    }
+    if (threadIdx.x == 0) {
+        dst.count = src->count;
+        dst.monotone = src->monotone;
+    }
+}
+
+// The shader scans i = 0 .. count-1 and returns at the first i with x[i] == s, or
+// x[i] <= s <= x[i+1] (x[count] is the never-written entry behind the curve: 0).
+// For a non-decreasing, NaN-free x[] that first match is i = j - 1 where j = #{x[i] < s}
+// (proof in DESIGN.md §Kernels/curve lookup), found here by a 6-step branch-free binary search;
+// otherwise the literal scan runs.
+__device__ __forceinline__ float curve_eval(const CurveLds& t, float s) {
+    const int count = (int)t.count;
+    if (t.monotone) {
+        int j = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            int probe = j + step;
+            if (probe <= count && t.x[probe - 1] < s) j = probe;
+        }
+        if (j == 0) return (t.x[0] == s) ? t.y[0] : 0.0f;
+        if (j >= count) return 0.0f;
+        return t.m[j - 1] * (s - t.x[j - 1]) + t.y[j - 1];
+    }
+    for (int i = 0; i < count; i++) {
+        float xi = t.x[i];
+        if (xi == s) return t.y[i];
+        float xn = (i + 1 < count) ? t.x[i + 1] : 0.0f;
+        float yn = (i + 1 < count) ? t.y[i + 1] : 0.0f;
+        if (xi <= s && xn >= s) {
+            float m = (yn - t.y[i]) / (xn - xi);
+            return m * (s - xi) + t.y[i];
+        }
+    }
+    return 0.0f;
+}
+
+// Fills m[] and monotone for a curve whose x[], y[], count are set (one thread).
+__device__ __forceinline__ void curve_finish(DevCurve* c) {
+    const int count = (int)c->count;
+    uint32_t mono = 1;
+    for (int i = 0; i < kCurveCap; i++) {
+        if (i + 1 < count) {
+            c->m[i] = (c->y[i + 1] - c->y[i]) / (c->x[i + 1] - c->x[i]);
+            if (!(c->x[i] <= c->x[i + 1])) mono = 0;
+        } else {
+            c->m[i] = 0.0f;
+        }
+        if (i >= count) {
+            c->x[i] = 0.0f;
+            c->y[i] = 0.0f;
+        }
+    }
+    if (count > 0 && !(c->x[0] == c->x[0])) mono = 0;
+    // the binary search probes up to 63 entries: keep count within that
+    if (count > 63) mono = 0;
+    c->monotone = mono;
+}
+
+// interpolate() of contrast_curve_generate.comp:28-31
+__device__ __forceinline__ float interpolate(float from, float to, float percent) {
+    float difference = to - from;
+    return from + (difference * percent);
+}
+
+// generateCurve(): contrast_curve_generate.comp:39-54 (steps 11) / gradation_curve_generate.comp:30-46 (steps 10)
+__device__ __forceinline__ void generate_curve(DevCurve* c, uint32_t& n, float sx, float sy, float mx, float my,
+                                               float ex, float ey, uint32_t steps) {
+    for (uint32_t i = 0; i < steps; i++) {
+        float t = (float)i / 10.0f;
+        float xa = interpolate(sx, mx, t);
+        float ya = interpolate(sy, my, t);
+        float xb = interpolate(mx, ex, t);
+        float yb = interpolate(my, ey, t);
+        c->x[n] = interpolate(xa, xb, t);
+        c->y[n] = interpolate(ya, yb, t);
+        n++;
+    }
+}
+
+}  // namespace musica

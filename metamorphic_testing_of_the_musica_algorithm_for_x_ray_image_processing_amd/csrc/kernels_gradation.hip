@@ -1,0 +1,291 @@
+// kernels_gradation.hip — gradation stage of the MUSICA path (gfx950).
+//
+//   k_grad_hist   : img_relevant.comp + gradation_histogram.comp fused        (K18 + K19)
+//   k_grad_curve  : img_histogram_max.comp + gradation_curve_generate.comp    (K12 + K20)
+//   k_grad_apply  : img_apply_gradation_curve.comp                            (K21)
+//   k_relevant    : img_relevant.comp alone (debug image, CLAHE input)
+#include <algorithm>
+#include "kernels_common.h"
+#include "launchers.h"
+
+namespace musica {
+
+// img_relevant.comp:28-64. `c` is cnr * 256 already. pow(r, 5.0) is restated as ((r*r)*(r*r))*r (oracle Q5).
+__device__ __forceinline__ float relevant_of(float pixel, float c, uint32_t x, uint32_t y, uint32_t N) {
+    const uint32_t border = 100u, lim = N - border;  // uint arithmetic as in the shader (wraps for N < 100)
+    const bool inside = x > border && x < lim && y > border && y < lim;
+    if (!inside) return 0.0f;
+    if (c >= 1.0f && c <= 6.0f) {
+        const float r = c / 6.0f;
+        return ((r * r) * (r * r)) * r;
+    }
+    if (c >= 6.0f && c <= kMaxCnrValue && pixel <= 0.90f) return 1.0f;
+    return 0.0f;
+}
+
+__device__ __forceinline__ float cnr_at(const float* __restrict__ cnr, int cnrS, int cnrPitch, int scale, int x, int y) {
+    const int cx = x / scale, cy = y / scale;
+    return ((cx < cnrS && cy < cnrS) ? cnr[(size_t)cy * cnrPitch + cx] : 0.0f) * kMaxCnrValue;
+}
+
+// gradation_histogram.comp:14-34 — the reference's thread (gx, gy) walks its 16x16 area column
+// by column (m = x outer, n = y inner) and `return`s at the first pixel that is exactly 0, so a
+// pixel at scan position m*16+n counts iff it precedes the area's first zero. Here a lane owns 4
+// columns of a 16-row group (one 16-byte load per row), finds its columns' first zeros, the 4 lanes
+// of an area combine them with two DPP/shuffle steps, and every pixel before that position is
+// binned with weight uint(relevant * 100) into an LDS-private histogram.
+__global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
+    __shared__ uint32_t lh[MUSICA_GRAD_BINS];
+    for (int i = threadIdx.x; i < MUSICA_GRAD_BINS; i += blockDim.x) lh[i] = 0u;
+    __syncthreads();
+    const int img = blockIdx.z;
+    const float* im = a.img + (size_t)img * a.plane;
+    const float* nm = a.normalized + (size_t)img * a.plane;
+    const float* cn = a.cnr + (size_t)img * a.cnrPlane;
+    const int lane = threadIdx.x & 63;
+    const int N = a.N;
+    const int c = blockIdx.x * 256 + lane * 4;
+    const int mbase = (lane & 3) * 4;
+    const int g0 = (blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)) * a.groups_per_wave;
+    for (int gi = 0; gi < a.groups_per_wave; gi++) {
+        const int yb = (g0 + gi) * kHistArea;
+        if (yb >= N) break;  // wave-uniform
+        float4 v[kHistArea];
+#pragma unroll
+        for (int n = 0; n < kHistArea; n++) {
+            const int y = yb + n;
+            v[n] = (y < N) ? load4_guard(im + (size_t)y * a.pitch, c, N) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // first zero of each owned column, as a scan position m*16 + n (256 = none)
+        int q = 256;
+#pragma unroll
+        for (int n = kHistArea - 1; n >= 0; n--) {
+            if (v[n].x == 0.0f) q = min(q, (mbase + 0) * 16 + n);
+            if (v[n].y == 0.0f) q = min(q, (mbase + 1) * 16 + n);
+            if (v[n].z == 0.0f) q = min(q, (mbase + 2) * 16 + n);
+            if (v[n].w == 0.0f) q = min(q, (mbase + 3) * 16 + n);
+        }
+        q = min(q, __shfl_xor(q, 1));
+        q = min(q, __shfl_xor(q, 2));
+        if (q == 0) continue;  // not wave-uniform, but nothing below crosses lanes
+#pragma unroll
+        for (int n = 0; n < kHistArea; n++) {
+            const int y = yb + n;
+            const float vv[4] = {v[n].x, v[n].y, v[n].z, v[n].w};
+            float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool have_pn = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if ((mbase + j) * 16 + n >= q) continue;
+                const float cur = vv[j];
+                if (cur != cur) continue;                                         // NaN never indexes (oracle Q6)
+                const float scaled = cur * (float)MUSICA_GRAD_BINS;                // gradation_histogram.comp:26
+                if (!(scaled > -2147483648.0f && scaled < 2147483648.0f)) continue;
+                const int bin = (int)scaled;
+                if (bin < 0 || bin >= MUSICA_GRAD_BINS) continue;                  // Q1
+                const int x = c + j;
+                const float cc = cnr_at(cn, a.cnrS, a.cnrPitch, a.cnrScale, x, y);
+                if (!(cc >= 1.0f)) continue;                                       // relevant == 0 -> adds 0
+                if (!have_pn) { pn = load4_guard(nm + (size_t)y * a.pitch, c, N); have_pn = true; }
+                const float pix = j == 0 ? pn.x : j == 1 ? pn.y : j == 2 ? pn.z : pn.w;
+                const uint32_t w = f2u(relevant_of(pix, cc, (uint32_t)x, (uint32_t)y, (uint32_t)N) * 100.0f);  // :28-30
+                if (w) atomicAdd(&lh[bin], w);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* gh = a.hist + (size_t)img * MUSICA_GRAD_BINS;
+    for (int i = threadIdx.x; i < MUSICA_GRAD_BINS; i += blockDim.x) {
+        const uint32_t v = lh[i];
+        if (v) atomicAdd(&gh[i], v);
+    }
+}
+
+// histogram from a stored relevant image (kernel-level parity tests, one thread per 16x16 area like the reference)
+__global__ void k_grad_hist_ref(const float* __restrict__ img, const float* __restrict__ relevant, int N, int pitch, size_t plane,
+                                uint32_t* __restrict__ hist) {
+    const int gx = blockIdx.x * blockDim.x + threadIdx.x, gy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int bx = gx * kHistArea, by = gy * kHistArea;
+    if (bx >= N || by >= N) return;
+    img += (size_t)blockIdx.z * plane;
+    relevant += (size_t)blockIdx.z * plane;
+    uint32_t* gh = hist + (size_t)blockIdx.z * MUSICA_GRAD_BINS;
+    for (int m = 0; m < kHistArea; m++)
+        for (int n = 0; n < kHistArea; n++) {
+            const int x = bx + m, y = by + n;
+            const float cur = (x < N && y < N) ? img[(size_t)y * pitch + x] : 0.0f;
+            if (cur == 0.0f) return;
+            if (cur != cur) continue;
+            const float scaled = cur * (float)MUSICA_GRAD_BINS;
+            if (!(scaled > -2147483648.0f && scaled < 2147483648.0f)) continue;
+            const int bin = (int)scaled;
+            if (bin < 0 || bin >= MUSICA_GRAD_BINS) continue;
+            const uint32_t w = f2u(relevant[(size_t)y * pitch + x] * 100.0f);
+            if (w) atomicAdd(&gh[bin], w);
+        }
+}
+
+__global__ void k_relevant(const float* __restrict__ normalized, const float* __restrict__ cnr, float* __restrict__ out, int N, int pitch,
+                           size_t plane, int cnrS, int cnrPitch, size_t cnrPlane, int cnrScale) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= N || y >= N) return;
+    const size_t o = (size_t)blockIdx.z * plane + (size_t)y * pitch + x;
+    const float cc = cnr_at(cnr + (size_t)blockIdx.z * cnrPlane, cnrS, cnrPitch, cnrScale, x, y);
+    out[o] = relevant_of(normalized[o], cc, (uint32_t)x, (uint32_t)y, (uint32_t)N);
+}
+
+// ---- K12 + K20 ------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t* scratch /*[16]*/) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) scratch[wv] = v;
+    __syncthreads();
+    uint32_t r = 0;
+    for (int i = 0; i < nw; i++) r += scratch[i];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ unsigned long long block_max_u64g(unsigned long long k, unsigned long long* scratch /*[16]*/) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long other = __shfl_xor(k, o);
+        k = other > k ? other : k;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) scratch[wv] = k;
+    __syncthreads();
+    unsigned long long r = 0ull;
+    for (int i = 0; i < nw; i++) r = scratch[i] > r ? scratch[i] : r;
+    __syncthreads();
+    return r;
+}
+
+// One block of 1024 threads per image: thread i owns bin i.
+// gradation_curve_generate.comp:50-193. All integer arithmetic is uint32 and wraps, like GLSL's uint.
+__global__ __launch_bounds__(1024) void k_grad_curve(const uint32_t* __restrict__ hist, musica_hist_max_point* __restrict__ gmax,
+                                                     DevCurve* __restrict__ curves) {
+    __shared__ uint32_t cnt[MUSICA_GRAD_BINS];
+    __shared__ uint32_t s32[16];
+    __shared__ unsigned long long s64[16];
+    const int img = blockIdx.x;
+    const uint32_t i = threadIdx.x;
+    const uint32_t raw = hist[(size_t)img * MUSICA_GRAD_BINS + i];
+    const uint32_t count = raw / 100u;                                           // :68
+    cnt[i] = count;
+    // K12 on the raw histogram (src/vk_processing.cpp:2499): first maximum wins
+    {
+        unsigned long long k = raw ? (((unsigned long long)raw << 32) | (unsigned long long)(0xFFFFFFFFu - i)) : 0ull;
+        k = block_max_u64g(k, s64);
+        if (i == 0) {
+            musica_hist_max_point mp;
+            mp.maxValue = k ? (uint32_t)(k >> 32) : 0u;
+            mp.maxBin = k ? 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull) : 0u;
+            gmax[img] = mp;
+        }
+    }
+    const uint32_t lowest = 10u;                                                 // :48
+    const uint32_t meanCount = block_sum_u32(i >= lowest ? count * i : 0u, s32); // :70 (wraps)
+    const uint32_t meanSum = block_sum_u32(i >= lowest ? count : 0u, s32);       // :71
+    const uint32_t meanQuot = meanSum ? meanCount / meanSum : 0u;                // :74 (x / 0 restated as 0)
+    const float meanHistPos = (float)meanQuot / (float)MUSICA_GRAD_BINS;
+    const uint32_t upper = f2u(meanHistPos * (float)MUSICA_GRAD_BINS);           // :77
+    // argmax over [lowest, upper), strict '>' scanning upwards: lowest index among the maxima; none -> (0, 0)
+    unsigned long long k = (i >= lowest && i < upper && count) ? (((unsigned long long)count << 32) | (unsigned long long)(0xFFFFFFFFu - i)) : 0ull;
+    k = block_max_u64g(k, s64);
+    const uint32_t maxCount = k ? (uint32_t)(k >> 32) : 0u;
+    const uint32_t maxPosition = k ? 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull) : 0u;
+    const uint32_t lowThreshold = f2u((float)maxCount * 0.05f);                  // :88
+    // t0 (:94-105): walk down from maxPosition to 1 while count >= lowThreshold; t0 = lowest bin reached.
+    // fail0 = highest bin in [1, maxPosition] violating the condition (0 if none).
+    unsigned long long f0 = (i >= 1 && i <= maxPosition && !(count >= lowThreshold)) ? (unsigned long long)i : 0ull;
+    f0 = block_max_u64g(f0, s64);
+    // t1 (:108-119): walk up from maxPosition while count > 0; t1 = highest bin reached.
+    // fail1 = lowest bin in [maxPosition, 1023] with count == 0 (1024 if none): max of (1024 - i).
+    unsigned long long f1 = (i >= maxPosition && count == 0u) ? (unsigned long long)(MUSICA_GRAD_BINS - i) : 0ull;
+    f1 = block_max_u64g(f1, s64);
+    if (i != 0) return;
+    const uint32_t fail0 = (uint32_t)f0;
+    const uint32_t fail1 = f1 ? (uint32_t)(MUSICA_GRAD_BINS - f1) : (uint32_t)MUSICA_GRAD_BINS;
+    float t0 = 0.0f, t1 = 0.0f;
+    if (maxPosition >= 1u && fail0 < maxPosition) t0 = (float)(fail0 + 1u) * (1.0f / (float)MUSICA_GRAD_BINS);   // :96-100
+    if (fail1 > maxPosition) t1 = (float)(fail1 - 1u) * (1.0f / (float)MUSICA_GRAD_BINS);                       // :110-115
+    float m = 3.0f;                                                              // :52
+    const float y_m = 0.5f;                                                      // :57
+    const float ta = (float)maxPosition * (1.0f / (float)MUSICA_GRAD_BINS);      // :121,:133
+    t0 -= 0.01f;                                                                 // :140
+    if (t0 < 0.0f) t0 = 0.0f;
+    if (t1 > 1.0f) t1 = 1.0f;                                                    // :144
+    float tf = -(0.5f / m) + ta;                                                 // :146
+    if (tf < t0) tf = t0;                                                        // :149
+    DevCurve* c = curves + img;
+    uint32_t n = 0;
+    c->x[n] = 0.0f; c->y[n] = 0.0f; n++;                                         // :152
+    generate_curve(c, n, t0, 0.0f, tf, 0.0f, ta, y_m, 10);                       // :156-160
+    if (tf == t0) m = y_m / (ta - tf);                                           // :162-163
+    const float ts = (y_m / m) + ta;                                             // :165
+    generate_curve(c, n, ta, y_m, ts, 1.0f, t1, 1.0f, 10);                       // :169-173
+    c->x[n] = 1.0f; c->y[n] = 1.0f; n++;                                         // :179
+    c->count = n;                                                                // :181
+    c->t0 = t0; c->ta = ta; c->t1 = t1;
+    curve_finish(c);
+}
+
+// ---- K21 ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grad_apply(const float* __restrict__ in, float* __restrict__ out, int N, int pitch, size_t plane,
+                                                    const DevCurve* __restrict__ curves) {
+    __shared__ CurveLds tab;
+    const int img = blockIdx.z;
+    curve_to_lds(tab, curves + img);
+    __syncthreads();
+    in += (size_t)img * plane;
+    out += (size_t)img * plane;
+    const int vec_per_row = pitch >> 2;
+    const size_t total = (size_t)vec_per_row * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / vec_per_row), x = (int)(i % vec_per_row) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(in + (size_t)y * pitch + x);
+        float4 o;
+        o.x = curve_eval(tab, v.x);                                             // img_apply_gradation_curve.comp:44
+        o.y = curve_eval(tab, v.y);
+        o.z = curve_eval(tab, v.z);
+        o.w = curve_eval(tab, v.w);
+        *reinterpret_cast<float4*>(out + (size_t)y * pitch + x) = o;
+    }
+}
+
+// ======================================================================================
+// host-side launchers
+// ======================================================================================
+
+void launch_grad_hist(hipStream_t st, const GradArgs& a, int batch) {
+    const int col_blocks = (a.N + 255) / 256;
+    const int groups = (a.N + kHistArea - 1) / kHistArea;
+    const int wave_rows = (groups + a.groups_per_wave - 1) / a.groups_per_wave;
+    hipLaunchKernelGGL(k_grad_hist, dim3(col_blocks, (wave_rows + kWavesPerBlock - 1) / kWavesPerBlock, batch), dim3(kBlockThreads), 0, st, a);
+}
+
+void launch_grad_hist_ref(hipStream_t st, const float* img, const float* relevant, const LevelDesc& l0, uint32_t* hist, int batch) {
+    const int areas = (l0.S + kHistArea - 1) / kHistArea;
+    hipLaunchKernelGGL(k_grad_hist_ref, dim3((areas + 15) / 16, (areas + 15) / 16, batch), dim3(16, 16), 0, st, img, relevant, l0.S, l0.pitch,
+                       l0.plane, hist);
+}
+
+void launch_relevant(hipStream_t st, const float* normalized, const float* cnr, float* out, const LevelDesc& l0, const LevelDesc& l3,
+                     int cnrScale, int batch) {
+    hipLaunchKernelGGL(k_relevant, dim3((l0.S + 31) / 32, (l0.S + 7) / 8, batch), dim3(32, 8), 0, st, normalized, cnr, out, l0.S, l0.pitch,
+                       l0.plane, l3.S, l3.pitch, l3.plane, cnrScale);
+}
+
+void launch_grad_curve(hipStream_t st, const uint32_t* hist, musica_hist_max_point* gmax, DevCurve* curves, int batch) {
+    hipLaunchKernelGGL(k_grad_curve, dim3(batch), dim3(1024), 0, st, hist, gmax, curves);
+}
+
+void launch_grad_apply(hipStream_t st, const float* in, float* out, const LevelDesc& l0, const DevCurve* curves, int batch) {
+    const size_t total = (size_t)(l0.pitch >> 2) * l0.S;
+    int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)2048);
+    hipLaunchKernelGGL(k_grad_apply, dim3(blocks, 1, batch), dim3(256), 0, st, in, out, l0.S, l0.pitch, l0.plane, curves);
+}
+
+}  // namespace musica

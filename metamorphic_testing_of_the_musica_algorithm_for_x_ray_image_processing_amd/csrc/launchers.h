@@ -1,0 +1,71 @@
+// launchers.h — host-callable launch wrappers implemented in the kernel files, plus the
+// argument blocks they share with the dispatch script in musica_ctx.hip.
+#pragma once
+
+#include "musica_device.h"
+
+namespace musica {
+
+// How the contrast gain of a level is obtained (contrast_curve_apply.comp:61 with the curve of
+// contrast_curve_generate.comp:56-94):
+//   GAIN_CONST : levels >= 4 — the sdev image is never written there (src/vk_processing.cpp:2285), so
+//                getY(0) == points[0].y == highContrastFactor exactly;
+//   GAIN_RANGE : level 3 — two-point constant curve but a real sdev: getY(s) = 0*s + high for
+//                0 <= s <= 1 (== high for finite s), 0 for s > 1 or NaN;
+//   GAIN_CURVE : levels 0..2 — the 33-point polyline.
+enum { GAIN_CONST = 0, GAIN_RANGE = 1, GAIN_CURVE = 2 };
+
+struct ExpandArgs {
+    const float* prev;   // coarse reconstruction (or downsampled[L-1] for the first slot)
+    const float* band;
+    const float* sdev;   // GAIN_RANGE / GAIN_CURVE
+    const float* cnr;    // noise reduction (levels 0, 1)
+    float* recon;
+    const DevCurve* curves;  // curve of this level for image 0 (GAIN_CURVE)
+    int S, pitch; size_t plane;
+    int Sc, cpitch; size_t cplane;
+    int cnrS, cnrPitch; size_t cnrPlane;
+    int cnrScale;        // uint(ceil(S / float(cnrS))), noise_reduction.comp:38
+    float high;          // highContrastFactor of the level
+    float lowCnr, lowFactor, highCnr, highFactor;  // NoiseReductionParams of the level
+    int rows_per_wave;
+    size_t curve_stride; // DevCurve elements between consecutive images
+};
+
+struct GradArgs {
+    const float* img;        // expandImageStates[L-1]: the contrast-enhanced image
+    const float* normalized;
+    const float* cnr;
+    uint32_t* hist;          // [batch][1024]
+    int N, pitch; size_t plane;
+    int cnrS, cnrPitch; size_t cnrPlane;
+    int cnrScale;            // uint(ceil(N / float(cnrS))), img_relevant.comp:32
+    int groups_per_wave;     // 16-row groups each wavefront walks
+};
+
+// kernels_pyramid.hip
+void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave, bool force_generic);
+void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave, bool force_generic);
+void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch);
+void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic);
+void launch_exp_band(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch);
+// kernels_analysis.hip
+void launch_clear(hipStream_t st, uint32_t* minmax, uint32_t* noise_hist, uint32_t* grad_hist, uint32_t* clahe_hist, int batch);
+void launch_minmax(hipStream_t st, const uint16_t* px, int N, uint32_t* minmax, int batch);
+void launch_normalize(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, const uint32_t* minmax, int min_chain_exact, int batch);
+void launch_sqrt(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, int batch);
+void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch, int rows_per_wave);
+void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch);
+void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves, const musica_contrast_params* cparams, int levels, int batch);
+void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& l3, const musica_hist_max_point* maxpts, int levels, int batch);
+void launch_sum_image(hipStream_t st, const float* img, const LevelDesc& l, double* out, int batch);
+// kernels_gradation.hip
+void launch_grad_hist(hipStream_t st, const GradArgs& a, int batch);
+void launch_grad_hist_ref(hipStream_t st, const float* img, const float* relevant, const LevelDesc& l0, uint32_t* hist, int batch);
+void launch_relevant(hipStream_t st, const float* normalized, const float* cnr, float* out, const LevelDesc& l0, const LevelDesc& l3, int cnrScale, int batch);
+void launch_grad_curve(hipStream_t st, const uint32_t* hist, musica_hist_max_point* gmax, DevCurve* curves, int batch);
+void launch_grad_apply(hipStream_t st, const float* in, float* out, const LevelDesc& l0, const DevCurve* curves, int batch);
+// kernels_clahe.hip
+void launch_clahe(hipStream_t st, const float* img, const float* relevant, float* out, const LevelDesc& l0, uint32_t* hist, musica_point* pts, int batch);
+
+}  // namespace musica

@@ -1,0 +1,867 @@
+// musica_ctx.hip — host side of libmusica_hip.so: the context that replaces class VulkanProcessing
+// (include/vk_processing.h:26-356 of the reference), the dispatch script that replaces
+// VulkanProcessing::execute (src/vk_processing.cpp:2104-2601) and the extern "C" boundary of
+// include/musica.h. No CPU fallback exists: without a HIP device musica_create fails loudly.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "launchers.h"
+
+// host-only helpers implemented in musica_io.cpp
+extern "C" int musica_write_bmp_gray(const char* path, uint32_t w, uint32_t h, const uint8_t* data);
+
+using namespace musica;
+
+// ---- errors ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    fprintf(stderr, "MUSICA ERROR: %s\n", buf);  // cf. "VK STATE ERROR: %s" src/vk_processing.cpp:14-18
+    return 0;
+}
+
+#define HIP_OK(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) return fail("%s failed: %s", #call, hipGetErrorString(e_));  \
+    } while (0)
+
+// ---- context --------------------------------------------------------------------------
+struct ProfSpan {
+    int id;
+    hipEvent_t a, b;
+};
+
+struct musica_ctx {
+    musica_params p;
+    int N, L, B;
+    bool generic;
+    LevelDesc lv[MUSICA_MAX_LEVELS + 1];
+    int min_chain_exact;
+    int hist_cov;  // (N / 512) * 512
+    hipStream_t stream;
+    // device state
+    uint16_t* d_input;
+    const uint16_t* cur_input;
+    uint32_t* d_minmax;
+    float* d_norm;
+    float* d_down[MUSICA_MAX_LEVELS];
+    float* d_band[MUSICA_MAX_LEVELS];
+    float* d_recon[MUSICA_MAX_LEVELS];
+    float* d_sdev[4];
+    uint32_t* d_noise_hist;
+    musica_hist_max_point* d_noise_max;
+    DevCurve* d_curves;
+    musica_contrast_params* d_cparams;
+    float* d_cnr;
+    uint32_t* d_grad_hist;
+    musica_hist_max_point* d_grad_max;
+    DevCurve* d_gcurve;
+    float* d_graded;
+    float* d_scratch;
+    double* d_sum;
+    uint32_t* d_clahe_hist;
+    musica_point* d_clahe_pts;
+    float* d_clahe_graded;
+    // host parameters (src/vk_processing.cpp:259-297, 321-325)
+    musica_contrast_params h_cparams[MUSICA_MAX_LEVELS];
+    musica_nr_params h_nr[3];
+    // tunables
+    int reduce_rows, band_rows, expand_rows, sdev_rows, grad_groups;
+    // profiling
+    bool profiling;
+    std::vector<ProfSpan> spans;
+    size_t spans_used;
+    double prof_total_us[MUSICA_KERNEL_COUNT];
+    uint64_t prof_count[MUSICA_KERNEL_COUNT];
+    std::vector<void*> allocations;
+};
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+template <typename T>
+static bool dalloc(musica_ctx* c, T** out, size_t count) {
+    void* p = nullptr;
+    if (count == 0) count = 1;
+    if (hipMalloc(&p, count * sizeof(T)) != hipSuccess) return false;
+    if (hipMemset(p, 0, count * sizeof(T)) != hipSuccess) return false;  // "never-written texels read as 0" (Q2)
+    c->allocations.push_back(p);
+    *out = (T*)p;
+    return true;
+}
+
+// highContrastFactor / lowContrastFactor per level: src/vk_processing.cpp:259-293 (non-LINEAR branches).
+static musica_contrast_params host_contrast_params(uint32_t i, uint32_t levels) {
+    const uint32_t coarserLevelsStart = MUSICA_COARSER_LEVELS_START;
+    const float highContrastMaxReduction = 0.2f, lowContrastMaxEnhancment = 3.0f;  // vk_processing.h:48-49
+    musica_contrast_params cp;
+    const uint32_t coarserLevelsCount = levels - coarserLevelsStart;
+    if (i < coarserLevelsStart) cp.highContrastFactor = 1.0f;
+    else {
+        // the reference divides by (coarserLevelsCount - 1): 0/0 at L = 4 — taken as exponent 0 there
+        const float e = coarserLevelsCount > 1 ? (float)(i - coarserLevelsStart) / (float)(coarserLevelsCount - 1) : 0.0f;
+        cp.highContrastFactor = powf(highContrastMaxReduction, e);
+    }
+    cp.lowContrastFactor = i < coarserLevelsStart ? powf(lowContrastMaxEnhancment, 1.0f - ((float)i / (float)coarserLevelsStart)) : 1.0f;
+    return cp;
+}
+
+// src/vk_processing.cpp:321-325; the buffer bound to band level l is index l (:1518-1520).
+static musica_nr_params host_nr_params(uint32_t i) {
+    const float nrHighCnr = 9.0f, nrMaxHighFactor = 1.2f, nrLowCnr = 3.0f, nrMinLowFactor = 0.6f;  // vk_processing.h:39-42
+    musica_nr_params q;
+    q.highCnr = nrHighCnr;
+    q.highFactor = nrMaxHighFactor - (nrMaxHighFactor - 1.0f) * ((float)i / (float)MUSICA_CNR_LEVEL);
+    q.lowCnr = nrLowCnr;
+    q.lowFactor = nrMinLowFactor + (1.0f - nrMinLowFactor) * ((float)i / (float)MUSICA_CNR_LEVEL);
+    return q;
+}
+
+static uint32_t cnr_scale(int S, int cnrS) { return (uint32_t)ceilf((float)S / (float)cnrS); }  // noise_reduction.comp:38
+
+static int pick_rows(int dflt, int min_rows, int S, int rows_total, int batch) {
+    int rpw = dflt;
+    const int strips = (S + kStripCols - 1) / kStripCols;
+    while (rpw > min_rows) {
+        const long waves = (long)strips * ((rows_total + rpw - 1) / rpw) * batch;
+        if (waves >= 2048) break;
+        rpw /= 2;
+    }
+    return rpw < min_rows ? min_rows : rpw;
+}
+
+extern "C" {
+
+uint32_t musica_abi_version(void) { return MUSICA_ABI_VERSION; }
+const char* musica_last_error(void) { return g_last_error.c_str(); }
+
+int musica_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void musica_destroy(musica_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->p.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    for (void* p : c->allocations) hipFree(p);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+musica_ctx* musica_create(const musica_params* params) {
+    if (!params) { fail("musica_create: params is NULL"); return nullptr; }
+    const uint32_t N = params->image_size;
+    if (N < 16 || N > 32768) { fail("musica_create: image_size %u out of range [16, 32768]", N); return nullptr; }
+    uint32_t Lref = 0;
+    while ((1u << Lref) < N) Lref++;  // pyramidLevels = ceil(log2(imageSize)), src/vk_processing.cpp:1989
+    const uint32_t L = params->levels ? params->levels : Lref;
+    if (L < MUSICA_MIN_LEVELS || L > Lref || L > MUSICA_MAX_LEVELS) {
+        fail("musica_create: levels %u out of range [%d, %u] for image_size %u", L, MUSICA_MIN_LEVELS, Lref, N);
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fail("musica_create: no HIP device available (this library has no CPU path)");
+        return nullptr;
+    }
+    if (params->device < 0 || params->device >= ndev) { fail("musica_create: device %d out of range (%d devices)", params->device, ndev); return nullptr; }
+    if (hipSetDevice(params->device) != hipSuccess) { fail("musica_create: hipSetDevice(%d) failed", params->device); return nullptr; }
+
+    musica_ctx* c = new musica_ctx();
+    c->p = *params;
+    c->N = (int)N; c->L = (int)L; c->B = params->batch ? (int)params->batch : 1;
+    c->p.levels = L; c->p.batch = (uint32_t)c->B;
+    c->generic = (params->flags & MUSICA_FLAG_GENERIC_KERNELS) != 0;
+    c->stream = nullptr; c->profiling = false; c->spans_used = 0; c->cur_input = nullptr;
+    memset(c->prof_total_us, 0, sizeof(c->prof_total_us));
+    memset(c->prof_count, 0, sizeof(c->prof_count));
+    int s = (int)N;
+    for (int i = 0; i <= c->L; i++) {
+        c->lv[i].S = s;
+        c->lv[i].pitch = round_up4(s);
+        c->lv[i].plane = (size_t)c->lv[i].pitch * s;
+        s = (s + 1) / 2;  // ceil(currentImageSize / 2.0f), src/vk_processing.cpp:116,150
+    }
+    { uint32_t n = N; while (n % 8 == 0) n /= 8; c->min_chain_exact = (n == 1); }
+    c->hist_cov = (int)(N / 512u) * 512;  // imageSize / histWorkgroupCoverage groups, src/vk_processing.cpp:2293-2295
+    for (int i = 0; i < c->L; i++) c->h_cparams[i] = host_contrast_params((uint32_t)i, L);
+    for (int i = 0; i < 3; i++) c->h_nr[i] = host_nr_params((uint32_t)i);
+    c->reduce_rows = env_int("MUSICA_REDUCE_ROWS", 16);
+    c->band_rows = env_int("MUSICA_BAND_ROWS", 8);
+    c->expand_rows = env_int("MUSICA_EXPAND_ROWS", 8);
+    c->sdev_rows = env_int("MUSICA_SDEV_ROWS", 32) & ~15;
+    if (c->sdev_rows < 16) c->sdev_rows = 16;
+    c->grad_groups = env_int("MUSICA_GRAD_GROUPS", 1);
+    if (c->grad_groups < 1) c->grad_groups = 1;
+
+    const size_t B = (size_t)c->B;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && dalloc(c, &c->d_input, B * N * N);
+    ok = ok && dalloc(c, &c->d_minmax, B * 2);
+    ok = ok && dalloc(c, &c->d_norm, B * c->lv[0].plane);
+    for (int i = 0; i < c->L && ok; i++) {
+        ok = ok && dalloc(c, &c->d_down[i], B * c->lv[i + 1].plane);
+        ok = ok && dalloc(c, &c->d_band[i], B * c->lv[i].plane);
+        ok = ok && dalloc(c, &c->d_recon[i], B * c->lv[i].plane);
+        if (i <= MUSICA_CNR_LEVEL) ok = ok && dalloc(c, &c->d_sdev[i], B * c->lv[i].plane);
+    }
+    ok = ok && dalloc(c, &c->d_noise_hist, B * 4 * MUSICA_NOISE_BINS);
+    ok = ok && dalloc(c, &c->d_noise_max, B * L);
+    ok = ok && dalloc(c, &c->d_curves, B * L);
+    ok = ok && dalloc(c, &c->d_cparams, (size_t)L);
+    ok = ok && dalloc(c, &c->d_cnr, B * c->lv[MUSICA_CNR_LEVEL].plane);
+    ok = ok && dalloc(c, &c->d_grad_hist, B * MUSICA_GRAD_BINS);
+    ok = ok && dalloc(c, &c->d_grad_max, B);
+    ok = ok && dalloc(c, &c->d_gcurve, B);
+    ok = ok && dalloc(c, &c->d_graded, B * c->lv[0].plane);
+    ok = ok && dalloc(c, &c->d_scratch, B * c->lv[0].plane);
+    ok = ok && dalloc(c, &c->d_sum, B);
+    c->d_clahe_hist = nullptr; c->d_clahe_pts = nullptr; c->d_clahe_graded = nullptr;
+    if (ok && (params->flags & MUSICA_FLAG_CLAHE)) {
+        const size_t tb = MUSICA_CLAHE_TILES * MUSICA_CLAHE_TILES * MUSICA_CLAHE_BINS;
+        ok = ok && dalloc(c, &c->d_clahe_hist, B * tb);
+        ok = ok && dalloc(c, &c->d_clahe_pts, B * tb);
+        ok = ok && dalloc(c, &c->d_clahe_graded, B * c->lv[0].plane);
+    }
+    ok = ok && hipMemcpy(c->d_cparams, c->h_cparams, sizeof(musica_contrast_params) * L, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        fail("musica_create: device allocation failed (%s)", hipGetErrorString(hipGetLastError()));
+        musica_destroy(c);
+        return nullptr;
+    }
+    c->cur_input = c->d_input;
+    return c;
+}
+
+uint32_t musica_get_image_size(const musica_ctx* c) { return c ? (uint32_t)c->N : 0; }
+uint32_t musica_get_levels(const musica_ctx* c) { return c ? (uint32_t)c->L : 0; }
+uint32_t musica_get_batch(const musica_ctx* c) { return c ? (uint32_t)c->B : 0; }
+uint32_t musica_get_level_size(const musica_ctx* c, uint32_t level) { return (c && (int)level <= c->L) ? (uint32_t)c->lv[level].S : 0; }
+
+}  // extern "C"
+
+// ---- profiling spans --------------------------------------------------------------------
+struct Span {
+    musica_ctx* c;
+    ProfSpan* s;
+    Span(musica_ctx* ctx, int id) : c(ctx), s(nullptr) {
+        if (!c->profiling) return;
+        if (c->spans_used == c->spans.size()) {
+            ProfSpan n;
+            n.id = id;
+            hipEventCreate(&n.a);
+            hipEventCreate(&n.b);
+            c->spans.push_back(n);
+        }
+        s = &c->spans[c->spans_used++];
+        s->id = id;
+        hipEventRecord(s->a, c->stream);
+    }
+    ~Span() {
+        if (s) hipEventRecord(s->b, c->stream);
+    }
+};
+
+static void collect_spans(musica_ctx* c) {
+    for (size_t i = 0; i < c->spans_used; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->spans[i].a, c->spans[i].b) == hipSuccess) {
+            c->prof_total_us[c->spans[i].id] += (double)ms * 1000.0;
+            c->prof_count[c->spans[i].id] += 1;
+        }
+    }
+    c->spans_used = 0;
+}
+
+// ---- the dispatch script ----------------------------------------------------------------
+static const float* level_input(musica_ctx* c, int i) { return i == 0 ? c->d_norm : c->d_down[i - 1]; }  // src/vk_processing.cpp:758-761
+
+// stage "norm" (src/vk_processing.cpp:2182-2222)
+static void enqueue_norm(musica_ctx* c) {
+    { Span sp(c, MUSICA_KERNEL_MINMAX); launch_minmax(c->stream, c->cur_input, c->N, c->d_minmax, c->B); }
+    { Span sp(c, MUSICA_KERNEL_NORMALIZE); launch_normalize(c->stream, c->cur_input, c->d_norm, c->lv[0], c->d_minmax, c->min_chain_exact, c->B); }
+}
+
+// stage "red" (src/vk_processing.cpp:2233-2273)
+static void enqueue_reduce(musica_ctx* c) {
+    for (int i = 0; i < c->L; i++) {
+        const LevelDesc& lf = c->lv[i];
+        const LevelDesc& lc = c->lv[i + 1];
+        {
+            Span sp(c, i == 0 ? MUSICA_KERNEL_REDUCE_L0 : MUSICA_KERNEL_REDUCE_REST);
+            launch_reduce(c->stream, level_input(c, i), lf, c->d_down[i], lc, c->B, pick_rows(c->reduce_rows, 4, lf.S, lc.S, c->B), c->generic);
+        }
+        {
+            Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST);
+            launch_band(c->stream, level_input(c, i), c->d_down[i], c->d_band[i], lf, lc, c->B, pick_rows(c->band_rows, 2, lf.S, lc.S, c->B), c->generic);
+        }
+    }
+}
+
+// stage "anly" (src/vk_processing.cpp:2284-2357)
+static void enqueue_analysis(musica_ctx* c) {
+    for (int i = 0; i <= MUSICA_CNR_LEVEL; i++) {  // i < coarserLevelsStart || i <= cnrLevel, :2285
+        Span sp(c, MUSICA_KERNEL_SDEV_HIST);
+        launch_sdev_hist(c->stream, c->d_band[i], c->d_sdev[i], c->lv[i], c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS,
+                         (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov, c->B, pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, c->B));
+    }
+    {
+        Span sp(c, MUSICA_KERNEL_CURVES);
+        launch_noise_curves(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B);
+    }
+    {
+        Span sp(c, MUSICA_KERNEL_CNR);
+        launch_cnr(c->stream, c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_noise_max, c->L, c->B);
+    }
+}
+
+static ExpandArgs expand_args(musica_ctx* c, int lvl, float* dst) {
+    const LevelDesc& lf = c->lv[lvl];
+    const LevelDesc& lc = c->lv[lvl + 1];
+    const LevelDesc& l3 = c->lv[MUSICA_CNR_LEVEL];
+    ExpandArgs a;
+    a.prev = lvl == c->L - 1 ? c->d_down[c->L - 1] : c->d_recon[lvl + 1];  // src/vk_processing.cpp:930-934
+    a.band = c->d_band[lvl];
+    a.sdev = lvl <= MUSICA_CNR_LEVEL ? c->d_sdev[lvl] : nullptr;
+    a.cnr = c->d_cnr;
+    a.recon = dst;
+    a.curves = c->d_curves + lvl;
+    a.curve_stride = (size_t)c->L;
+    a.S = lf.S; a.pitch = lf.pitch; a.plane = lf.plane;
+    a.Sc = lc.S; a.cpitch = lc.pitch; a.cplane = lc.plane;
+    a.cnrS = l3.S; a.cnrPitch = l3.pitch; a.cnrPlane = l3.plane;
+    a.cnrScale = (int)cnr_scale(lf.S, l3.S);
+    a.high = c->h_cparams[lvl].highContrastFactor;
+    const musica_nr_params& q = c->h_nr[lvl < 3 ? lvl : 0];
+    a.lowCnr = q.lowCnr; a.lowFactor = q.lowFactor; a.highCnr = q.highCnr; a.highFactor = q.highFactor;
+    a.rows_per_wave = pick_rows(c->expand_rows, 2, lf.S, lc.S, c->B);
+    return a;
+}
+static int gain_mode(int lvl) { return lvl > MUSICA_CNR_LEVEL ? GAIN_CONST : (lvl == MUSICA_CNR_LEVEL ? GAIN_RANGE : GAIN_CURVE); }
+static bool uses_nr(int lvl) { return lvl < MUSICA_CNR_LEVEL - 1; }  // currentLevel < cnrLevel - 1, src/vk_processing.cpp:1009-1016
+
+// stages "aply" + "exp" (src/vk_processing.cpp:2361-2431)
+static void enqueue_expand(musica_ctx* c) {
+    for (int lvl = c->L - 1; lvl >= 0; lvl--) {
+        Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
+        const ExpandArgs a = expand_args(c, lvl, c->d_recon[lvl]);
+        launch_expand(c->stream, a, gain_mode(lvl), uses_nr(lvl), c->B, c->generic);
+    }
+}
+
+// stage "grad" (src/vk_processing.cpp:2456-2518)
+static void enqueue_gradation(musica_ctx* c) {
+    const LevelDesc& l0 = c->lv[0];
+    const LevelDesc& l3 = c->lv[MUSICA_CNR_LEVEL];
+    const int scale = (int)cnr_scale(l0.S, l3.S);
+    if (c->d_clahe_hist) {  // #ifdef ENABLE_CLAHE block, src/vk_processing.cpp:2471-2489
+        launch_relevant(c->stream, c->d_norm, c->d_cnr, c->d_scratch, l0, l3, scale, c->B);
+        launch_clahe(c->stream, c->d_recon[0], c->d_scratch, c->d_clahe_graded, l0, c->d_clahe_hist, c->d_clahe_pts, c->B);
+    }
+    {
+        Span sp(c, MUSICA_KERNEL_GRAD_HIST);
+        GradArgs g;
+        g.img = c->d_recon[0]; g.normalized = c->d_norm; g.cnr = c->d_cnr; g.hist = c->d_grad_hist;
+        g.N = l0.S; g.pitch = l0.pitch; g.plane = l0.plane;
+        g.cnrS = l3.S; g.cnrPitch = l3.pitch; g.cnrPlane = l3.plane; g.cnrScale = scale;
+        g.groups_per_wave = c->grad_groups;
+        launch_grad_hist(c->stream, g, c->B);
+    }
+    { Span sp(c, MUSICA_KERNEL_GRAD_CURVE); launch_grad_curve(c->stream, c->d_grad_hist, c->d_grad_max, c->d_gcurve, c->B); }
+    { Span sp(c, MUSICA_KERNEL_GRAD_APPLY); launch_grad_apply(c->stream, c->d_recon[0], c->d_graded, l0, c->d_gcurve, c->B); }
+}
+
+static int enqueue_all(musica_ctx* c) {
+    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B);  // :2153-2162
+    enqueue_norm(c);
+    enqueue_reduce(c);
+    enqueue_analysis(c);
+    enqueue_expand(c);
+    enqueue_gradation(c);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e));
+    return 1;
+}
+
+// pitched device plane -> dense host image
+static int download_plane(musica_ctx* c, const float* d_plane, const LevelDesc& l, float* dst) {
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy2D(dst, (size_t)l.S * sizeof(float), d_plane, (size_t)l.pitch * sizeof(float), (size_t)l.S * sizeof(float), (size_t)l.S,
+                       hipMemcpyDeviceToHost));
+    return 1;
+}
+static int upload_plane(musica_ctx* c, float* d_plane, const LevelDesc& l, const float* src) {
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy2D(d_plane, (size_t)l.pitch * sizeof(float), src, (size_t)l.S * sizeof(float), (size_t)l.S * sizeof(float), (size_t)l.S,
+                       hipMemcpyHostToDevice));
+    return 1;
+}
+
+template <typename T>
+static int download_small(musica_ctx* c, const T* d_src, T* dst, size_t count) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(dst, d_src, count * sizeof(T), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail("device read-back failed: %s", hipGetErrorString(e));
+    return 1;
+}
+
+#define CHECK_CTX(c) do { if (!(c)) return fail("%s: ctx is NULL", __func__); if (hipSetDevice((c)->p.device) != hipSuccess) return fail("%s: hipSetDevice failed", __func__); } while (0)
+#define CHECK_IMG(c, idx) do { if ((int)(idx) >= (c)->B) return fail("%s: image_index %u >= batch %d", __func__, (unsigned)(idx), (c)->B); } while (0)
+
+extern "C" {
+
+int musica_sync(musica_ctx* c) {
+    CHECK_CTX(c);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (c->profiling) collect_spans(c);
+    return 1;
+}
+
+int musica_upload(musica_ctx* c, const uint16_t* pixels) {
+    CHECK_CTX(c);
+    if (!pixels) return fail("musica_upload: pixels is NULL");
+    HIP_OK(hipMemcpyAsync(c->d_input, pixels, (size_t)c->B * c->N * c->N * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 1;
+}
+
+const uint16_t* musica_input_device_ptr(musica_ctx* c) { return c ? c->d_input : nullptr; }
+
+int musica_execute_device(musica_ctx* c, const uint16_t* d_pixels) {
+    CHECK_CTX(c);
+    if (!d_pixels) return fail("musica_execute_device: d_pixels is NULL");
+    if (((uintptr_t)d_pixels & 15u) != 0) return fail("musica_execute_device: d_pixels must be 16-byte aligned");
+    c->cur_input = d_pixels;
+    return enqueue_all(c);
+}
+
+int musica_execute(musica_ctx* c, const uint16_t* pixels) {
+    CHECK_CTX(c);
+    if (!pixels) return fail("musica_execute: pixels is NULL");
+    HIP_OK(hipMemcpyAsync(c->d_input, pixels, (size_t)c->B * c->N * c->N * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));  // vk_state.cpp:313-342
+    c->cur_input = c->d_input;
+    if (!enqueue_all(c)) return 0;
+    return musica_sync(c);  // vkWaitForFences, src/vk_processing.cpp:2535-2536
+}
+
+int musica_debug_run_stage(musica_ctx* c, musica_stage stage) {
+    CHECK_CTX(c);
+    switch (stage) {
+        case MUSICA_STAGE_NORM:
+            launch_clear(c->stream, c->d_minmax, nullptr, nullptr, nullptr, c->B);
+            enqueue_norm(c);
+            break;
+        case MUSICA_STAGE_REDUCE: enqueue_reduce(c); break;
+        case MUSICA_STAGE_ANALYSIS:
+            launch_clear(c->stream, nullptr, c->d_noise_hist, nullptr, nullptr, c->B);
+            enqueue_analysis(c);
+            break;
+        case MUSICA_STAGE_EXPAND: enqueue_expand(c); break;
+        case MUSICA_STAGE_GRADATION:
+            launch_clear(c->stream, nullptr, nullptr, c->d_grad_hist, c->d_clahe_hist, c->B);
+            enqueue_gradation(c);
+            break;
+        default: return fail("musica_debug_run_stage: unknown stage %d", (int)stage);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e));
+    return musica_sync(c);
+}
+
+uint32_t musica_image_side(const musica_ctx* c, musica_image_kind kind, uint32_t level) {
+    if (!c) return 0;
+    switch (kind) {
+        case MUSICA_IMG_NORMALIZED: case MUSICA_IMG_GRADED: case MUSICA_IMG_RELEVANT: case MUSICA_IMG_SQRT: case MUSICA_IMG_CLAHE_GRADED:
+            return level == 0 ? (uint32_t)c->N : 0;
+        case MUSICA_IMG_CNR: return level == MUSICA_CNR_LEVEL ? (uint32_t)c->lv[MUSICA_CNR_LEVEL].S : 0;
+        case MUSICA_IMG_DOWNSAMPLED: return (int)level < c->L ? (uint32_t)c->lv[level + 1].S : 0;
+        case MUSICA_IMG_BANDPASS: case MUSICA_IMG_SDEV: case MUSICA_IMG_EXPAND: case MUSICA_IMG_LOWPASS: case MUSICA_IMG_EXP_BANDPASS:
+            return (int)level < c->L ? (uint32_t)c->lv[level].S : 0;
+        default: return 0;
+    }
+}
+
+// Resolves (kind, level) to a device plane of image `idx`; on-demand kinds are computed into d_scratch.
+static int resolve_image(musica_ctx* c, uint32_t idx, musica_image_kind kind, uint32_t level, const float** plane, const LevelDesc** desc) {
+    if (musica_image_side(c, kind, level) == 0) return fail("musica_get_image: no image kind=%d level=%u", (int)kind, level);
+    const LevelDesc& l0 = c->lv[0];
+    const LevelDesc& l3 = c->lv[MUSICA_CNR_LEVEL];
+    switch (kind) {
+        case MUSICA_IMG_NORMALIZED: *plane = c->d_norm + idx * l0.plane; *desc = &c->lv[0]; return 1;
+        case MUSICA_IMG_GRADED: *plane = c->d_graded + idx * l0.plane; *desc = &c->lv[0]; return 1;
+        case MUSICA_IMG_CLAHE_GRADED:
+            if (!c->d_clahe_graded) return fail("musica_get_image: ctx was created without MUSICA_FLAG_CLAHE");
+            *plane = c->d_clahe_graded + idx * l0.plane; *desc = &c->lv[0]; return 1;
+        case MUSICA_IMG_CNR: *plane = c->d_cnr + idx * l3.plane; *desc = &c->lv[MUSICA_CNR_LEVEL]; return 1;
+        case MUSICA_IMG_DOWNSAMPLED: *plane = c->d_down[level] + idx * c->lv[level + 1].plane; *desc = &c->lv[level + 1]; return 1;
+        case MUSICA_IMG_BANDPASS: *plane = c->d_band[level] + idx * c->lv[level].plane; *desc = &c->lv[level]; return 1;
+        case MUSICA_IMG_EXPAND: *plane = c->d_recon[level] + idx * c->lv[level].plane; *desc = &c->lv[level]; return 1;
+        case MUSICA_IMG_SDEV:
+            *desc = &c->lv[level];
+            if (level <= MUSICA_CNR_LEVEL) { *plane = c->d_sdev[level] + idx * c->lv[level].plane; return 1; }
+            // levels >= 4: the reference never writes these images (src/vk_processing.cpp:2285) -> zeros (Q2)
+            HIP_OK(hipMemsetAsync(c->d_scratch, 0, c->lv[level].plane * sizeof(float), c->stream));
+            *plane = c->d_scratch; return 1;
+        case MUSICA_IMG_RELEVANT:
+            launch_relevant(c->stream, c->d_norm, c->d_cnr, c->d_scratch, l0, l3, (int)cnr_scale(l0.S, l3.S), c->B);
+            *plane = c->d_scratch + idx * l0.plane; *desc = &c->lv[0]; return 1;
+        case MUSICA_IMG_SQRT:
+            launch_sqrt(c->stream, c->cur_input, c->d_scratch, l0, c->B);
+            *plane = c->d_scratch + idx * l0.plane; *desc = &c->lv[0]; return 1;
+        case MUSICA_IMG_LOWPASS:  // lowpassImageStates[level] = smooth_upsampled(upsample(downsampled[level]))
+            launch_lowpass(c->stream, c->d_down[level], c->d_scratch, c->lv[level], c->lv[level + 1], c->B);
+            *plane = c->d_scratch + idx * c->lv[level].plane; *desc = &c->lv[level]; return 1;
+        case MUSICA_IMG_EXP_BANDPASS: {
+            const ExpandArgs a = expand_args(c, (int)level, c->d_scratch);
+            launch_exp_band(c->stream, a, gain_mode((int)level), uses_nr((int)level), c->B);
+            *plane = c->d_scratch + idx * c->lv[level].plane; *desc = &c->lv[level]; return 1;
+        }
+        default: return fail("musica_get_image: unsupported kind %d", (int)kind);
+    }
+}
+
+int musica_get_image(musica_ctx* c, uint32_t idx, musica_image_kind kind, uint32_t level, float* dst) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    if (!dst) return fail("musica_get_image: dst is NULL");
+    const float* plane = nullptr;
+    const LevelDesc* d = nullptr;
+    if (!resolve_image(c, idx, kind, level, &plane, &d)) return 0;
+    return download_plane(c, plane, *d, dst);
+}
+
+int musica_debug_set_image(musica_ctx* c, uint32_t idx, musica_image_kind kind, uint32_t level, const float* src) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    if (!src) return fail("musica_debug_set_image: src is NULL");
+    if (musica_image_side(c, kind, level) == 0) return fail("musica_debug_set_image: no image kind=%d level=%u", (int)kind, level);
+    switch (kind) {
+        case MUSICA_IMG_NORMALIZED: return upload_plane(c, c->d_norm + idx * c->lv[0].plane, c->lv[0], src);
+        case MUSICA_IMG_GRADED: return upload_plane(c, c->d_graded + idx * c->lv[0].plane, c->lv[0], src);
+        case MUSICA_IMG_CNR: return upload_plane(c, c->d_cnr + idx * c->lv[MUSICA_CNR_LEVEL].plane, c->lv[MUSICA_CNR_LEVEL], src);
+        case MUSICA_IMG_DOWNSAMPLED: return upload_plane(c, c->d_down[level] + idx * c->lv[level + 1].plane, c->lv[level + 1], src);
+        case MUSICA_IMG_BANDPASS: return upload_plane(c, c->d_band[level] + idx * c->lv[level].plane, c->lv[level], src);
+        case MUSICA_IMG_EXPAND: return upload_plane(c, c->d_recon[level] + idx * c->lv[level].plane, c->lv[level], src);
+        case MUSICA_IMG_SDEV:
+            if (level > MUSICA_CNR_LEVEL) return fail("musica_debug_set_image: sdev exists only for levels 0..3");
+            return upload_plane(c, c->d_sdev[level] + idx * c->lv[level].plane, c->lv[level], src);
+        default: return fail("musica_debug_set_image: kind %d is not stored on the hot path", (int)kind);
+    }
+}
+
+int musica_get_graded(musica_ctx* c, float* dst) {
+    CHECK_CTX(c);
+    if (!dst) return fail("musica_get_graded: dst is NULL");
+    for (int b = 0; b < c->B; b++)
+        if (!download_plane(c, c->d_graded + (size_t)b * c->lv[0].plane, c->lv[0], dst + (size_t)b * c->N * c->N)) return 0;
+    return 1;
+}
+
+// saveOutImage: crop margin 10, (uint8_t)(255.0f * (v - 0) / (1 - 0)) (src/vk_processing.cpp:2624-2634).
+int musica_get_out_pixels(musica_ctx* c, uint32_t idx, uint8_t* dst) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    if (!dst) return fail("musica_get_out_pixels: dst is NULL");
+    const uint32_t N = (uint32_t)c->N, margin = MUSICA_OUT_MARGIN;
+    if (N <= 2 * margin) return fail("musica_get_out_pixels: image too small for the %u-pixel margin", margin);
+    std::vector<float> g((size_t)N * N);
+    if (!download_plane(c, c->d_graded + (size_t)idx * c->lv[0].plane, c->lv[0], g.data())) return 0;
+    const uint32_t nw = N - 2 * margin;
+    const float maxValue = 1.0f, minValue = 0.0f;
+    for (uint32_t y = 0; y < nw; y++)
+        for (uint32_t x = 0; x < nw; x++) {
+            const float q = 255.0f * (g[(size_t)(y + margin) * N + x + margin] - minValue) / (maxValue - minValue);
+            dst[(size_t)y * nw + x] = (uint8_t)(int32_t)q;
+        }
+    return 1;
+}
+
+int musica_save_out_image(musica_ctx* c, uint32_t idx, const char* path) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    if (!path) return fail("musica_save_out_image: path is NULL");
+    const uint32_t nw = (uint32_t)c->N - 2 * MUSICA_OUT_MARGIN;
+    std::vector<uint8_t> buf((size_t)nw * nw);
+    if (!musica_get_out_pixels(c, idx, buf.data())) return 0;
+    if (!musica_write_bmp_gray(path, nw, nw, buf.data())) return fail("failed to write out file");  // :2636-2642
+    return 1;
+}
+
+int musica_get_noise_hist(musica_ctx* c, uint32_t idx, uint32_t level, uint32_t* dst) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    if ((int)level >= c->L) return fail("musica_get_noise_hist: level %u >= %d", level, c->L);
+    if (level > MUSICA_CNR_LEVEL) { memset(dst, 0, MUSICA_NOISE_BINS * sizeof(uint32_t)); return 1; }  // cleared, never filled
+    return download_small(c, c->d_noise_hist + ((size_t)idx * 4 + level) * MUSICA_NOISE_BINS, dst, MUSICA_NOISE_BINS);
+}
+int musica_get_grad_hist(musica_ctx* c, uint32_t idx, uint32_t* dst) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    return download_small(c, c->d_grad_hist + (size_t)idx * MUSICA_GRAD_BINS, dst, MUSICA_GRAD_BINS);
+}
+int musica_get_noise_hist_max(musica_ctx* c, uint32_t idx, uint32_t level, musica_hist_max_point* dst) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    if ((int)level >= c->L) return fail("musica_get_noise_hist_max: level %u >= %d", level, c->L);
+    return download_small(c, c->d_noise_max + (size_t)idx * c->L + level, dst, 1);
+}
+int musica_get_grad_hist_max(musica_ctx* c, uint32_t idx, musica_hist_max_point* dst) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    return download_small(c, c->d_grad_max + idx, dst, 1);
+}
+int musica_get_contrast_curve(musica_ctx* c, uint32_t idx, uint32_t level, musica_contrast_curve* dst) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    if ((int)level >= c->L) return fail("musica_get_contrast_curve: level %u >= %d", level, c->L);
+    DevCurve dc;
+    if (!download_small(c, c->d_curves + (size_t)idx * c->L + level, &dc, 1)) return 0;
+    memset(dst, 0, sizeof(*dst));
+    for (uint32_t i = 0; i < dc.count && i < MUSICA_MAX_POINTS; i++) { dst->points[i].x = dc.x[i]; dst->points[i].y = dc.y[i]; }
+    dst->pointsCount = dc.count;
+    return 1;
+}
+int musica_get_grad_curve(musica_ctx* c, uint32_t idx, musica_grad_curve* dst) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    DevCurve dc;
+    if (!download_small(c, c->d_gcurve + idx, &dc, 1)) return 0;
+    memset(dst, 0, sizeof(*dst));
+    for (uint32_t i = 0; i < dc.count && i < MUSICA_MAX_POINTS; i++) { dst->points[i].x = dc.x[i]; dst->points[i].y = dc.y[i]; }
+    dst->pointsCount = dc.count;
+    dst->t0 = dc.t0; dst->ta = dc.ta; dst->t1 = dc.t1;
+    return 1;
+}
+int musica_get_contrast_params(musica_ctx* c, uint32_t level, musica_contrast_params* dst) {
+    if (!c || (int)level >= c->L) return fail("musica_get_contrast_params: bad ctx/level");
+    *dst = c->h_cparams[level];
+    return 1;
+}
+int musica_get_nr_params(musica_ctx* c, uint32_t level, musica_nr_params* dst) {
+    if (!c || level >= 3) return fail("musica_get_nr_params: bad ctx/level");
+    *dst = c->h_nr[level];
+    return 1;
+}
+int musica_get_minmax(musica_ctx* c, uint32_t idx, float* min_sqrt, float* max_sqrt) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    uint32_t mm[2];
+    if (!download_small(c, c->d_minmax + 2 * (size_t)idx, mm, 2)) return 0;
+    // same scalars the normalize kernel derives (kernels_analysis.hip chain_scalars)
+    const float mx = sqrtf((float)mm[1]), mn = sqrtf((float)mm[0]);
+    *max_sqrt = (float)(uint32_t)mx;
+    *min_sqrt = c->min_chain_exact ? (float)(uint32_t)mn : 0.0f;
+    return 1;
+}
+int musica_get_stats(musica_ctx* c, uint32_t idx, musica_stats* dst) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    memset(dst, 0, sizeof(*dst));
+    dst->image_id = idx;
+    if (!musica_get_minmax(c, idx, &dst->min_sqrt, &dst->max_sqrt)) return 0;
+    for (uint32_t l = 0; l < 4; l++) {
+        musica_hist_max_point mp;
+        if (!musica_get_noise_hist_max(c, idx, l, &mp)) return 0;
+        dst->noise_max_bin[l] = mp.maxBin;
+        dst->noise_max_value[l] = mp.maxValue;
+    }
+    musica_hist_max_point gm;
+    if (!musica_get_grad_hist_max(c, idx, &gm)) return 0;
+    dst->grad_max_bin = gm.maxBin;
+    dst->grad_max_value = gm.maxValue;
+    const LevelDesc& l3 = c->lv[MUSICA_CNR_LEVEL];
+    launch_sum_image(c->stream, c->d_cnr, l3, c->d_sum, c->B);
+    double sum = 0.0;
+    if (!download_small(c, c->d_sum + idx, &sum, 1)) return 0;
+    dst->mean_cnr = (float)(sum / ((double)l3.S * l3.S) * 256.0);
+    DevCurve dc;
+    if (!download_small(c, c->d_gcurve + idx, &dc, 1)) return 0;
+    dst->t0 = dc.t0; dst->ta = dc.ta; dst->t1 = dc.t1;
+    return 1;
+}
+int musica_get_clahe_hist(musica_ctx* c, uint32_t idx, uint32_t* dst) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    if (!c->d_clahe_hist) return fail("musica_get_clahe_hist: ctx was created without MUSICA_FLAG_CLAHE");
+    const size_t tb = MUSICA_CLAHE_TILES * MUSICA_CLAHE_TILES * MUSICA_CLAHE_BINS;
+    return download_small(c, c->d_clahe_hist + idx * tb, dst, tb);
+}
+int musica_get_clahe_curves(musica_ctx* c, uint32_t idx, musica_point* dst) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    if (!c->d_clahe_pts) return fail("musica_get_clahe_curves: ctx was created without MUSICA_FLAG_CLAHE");
+    const size_t tb = MUSICA_CLAHE_TILES * MUSICA_CLAHE_TILES * MUSICA_CLAHE_BINS;
+    return download_small(c, c->d_clahe_pts + idx * tb, dst, tb);
+}
+
+// VulkanState::downloadAndSaveImage (src/vk_state.cpp:809-855): (uint8_t)(255 * (v - min) / (max - min)), full image.
+static int dump_image(musica_ctx* c, uint32_t idx, musica_image_kind kind, uint32_t level, const std::string& path, float maxValue, float minValue) {
+    const uint32_t side = musica_image_side(c, kind, level);
+    std::vector<float> img((size_t)side * side);
+    if (!musica_get_image(c, idx, kind, level, img.data())) return 0;
+    std::vector<uint8_t> out((size_t)side * side);
+    for (size_t i = 0; i < out.size(); i++) {
+        const float q = 255.0f * (img[i] - minValue) / (maxValue - minValue);
+        // the reference's C cast is undefined outside [0, 256); wrap like the common x86 lowering (cvttss2si + truncate)
+        out[i] = (q == q && q > -2147483648.0f && q < 2147483648.0f) ? (uint8_t)(int32_t)q : 0;
+    }
+    if (!musica_write_bmp_gray(path.c_str(), side, side, out.data())) return fail("failed to write %s", path.c_str());
+    return 1;
+}
+
+int musica_debug_process(musica_ctx* c, uint32_t idx, const char* dir) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    const std::string d = std::string(dir && *dir ? dir : ".") + "/";
+    if (!dump_image(c, idx, MUSICA_IMG_NORMALIZED, 0, d + "norm.bmp", 1.0f, 0.0f)) return 0;               // :2664-2671
+    for (int i = 0; i < c->L; i++) {                                                                       // :2673-2690
+        if (!dump_image(c, idx, MUSICA_IMG_BANDPASS, i, d + "red_bandpass_" + std::to_string(i) + ".bmp", 1.0f, -1.0f)) return 0;
+        if (!dump_image(c, idx, MUSICA_IMG_LOWPASS, i, d + "red_lowpass_" + std::to_string(i) + ".bmp", 1.0f, 0.0f)) return 0;
+    }
+    if (!dump_image(c, idx, MUSICA_IMG_SDEV, MUSICA_CNR_LEVEL, d + "sdev.bmp", 1.0f, -1.0f)) return 0;      // :2692-2699
+    if (!dump_image(c, idx, MUSICA_IMG_CNR, MUSICA_CNR_LEVEL, d + "cnr.bmp", 1.0f, 0.0f)) return 0;         // :2701-2708
+    for (int i = 0; i < c->L; i++) {                                                                       // :2710-2727 (slot i <-> level L-1-i)
+        const int lvl = c->L - 1 - i;
+        if (!dump_image(c, idx, MUSICA_IMG_EXP_BANDPASS, lvl, d + "exp_bandpass_" + std::to_string(i) + ".bmp", 1.0f, -1.0f)) return 0;
+        // expandLowpassImageStates[i] = smooth_upsampled(upsample(previous reconstruction))
+        const LevelDesc& lf = c->lv[lvl];
+        const float* prev = lvl == c->L - 1 ? c->d_down[c->L - 1] : c->d_recon[lvl + 1];
+        launch_lowpass(c->stream, prev, c->d_scratch, lf, c->lv[lvl + 1], c->B);
+        std::vector<float> img((size_t)lf.S * lf.S);
+        if (!download_plane(c, c->d_scratch + (size_t)idx * lf.plane, lf, img.data())) return 0;
+        std::vector<uint8_t> out(img.size());
+        for (size_t k = 0; k < out.size(); k++) {
+            const float q = 255.0f * img[k];
+            out[k] = (q == q && q > -2147483648.0f && q < 2147483648.0f) ? (uint8_t)(int32_t)q : 0;
+        }
+        if (!musica_write_bmp_gray((d + "exp_lowpass_" + std::to_string(i) + ".bmp").c_str(), lf.S, lf.S, out.data())) return fail("failed to write exp_lowpass");
+    }
+    if (!dump_image(c, idx, MUSICA_IMG_RELEVANT, 0, d + "relevant.bmp", 1.0f, 0.0f)) return 0;              // :2729-2736
+    if (!dump_image(c, idx, MUSICA_IMG_GRADED, 0, d + "graded.bmp", 1.0f, 0.0f)) return 0;                  // :2749-2756
+    // histograms and curves as CSV instead of the rendered RGBA plots (noise_hist.bmp / grad_hist.bmp, :2758-2806)
+    {
+        std::vector<uint32_t> h(MUSICA_NOISE_BINS);
+        FILE* f = fopen((d + "noise_hist.csv").c_str(), "w");
+        if (!f) return fail("failed to write noise_hist.csv");
+        fprintf(f, "bin,level0,level1,level2,level3\n");
+        std::vector<uint32_t> all(4 * MUSICA_NOISE_BINS);
+        for (uint32_t l = 0; l < 4; l++)
+            if (!musica_get_noise_hist(c, idx, l, all.data() + l * MUSICA_NOISE_BINS)) { fclose(f); return 0; }
+        for (int b = 0; b < MUSICA_NOISE_BINS; b++)
+            fprintf(f, "%d,%u,%u,%u,%u\n", b, all[b], all[MUSICA_NOISE_BINS + b], all[2 * MUSICA_NOISE_BINS + b], all[3 * MUSICA_NOISE_BINS + b]);
+        fclose(f);
+    }
+    {
+        std::vector<uint32_t> h(MUSICA_GRAD_BINS);
+        if (!musica_get_grad_hist(c, idx, h.data())) return 0;
+        musica_grad_curve gc;
+        if (!musica_get_grad_curve(c, idx, &gc)) return 0;
+        FILE* f = fopen((d + "grad_hist.csv").c_str(), "w");
+        if (!f) return fail("failed to write grad_hist.csv");
+        fprintf(f, "bin,weight\n");
+        for (int b = 0; b < MUSICA_GRAD_BINS; b++) fprintf(f, "%d,%u\n", b, h[b]);
+        fclose(f);
+        f = fopen((d + "grad_curve.csv").c_str(), "w");
+        if (!f) return fail("failed to write grad_curve.csv");
+        fprintf(f, "# t0=%.9g ta=%.9g t1=%.9g\nx,y\n", gc.t0, gc.ta, gc.t1);
+        for (uint32_t i = 0; i < gc.pointsCount; i++) fprintf(f, "%.9g,%.9g\n", gc.points[i].x, gc.points[i].y);
+        fclose(f);
+    }
+    return 1;
+}
+
+// ---- profiling ------------------------------------------------------------------------
+int musica_profile_enable(musica_ctx* c, int enabled) {
+    CHECK_CTX(c);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    collect_spans(c);
+    c->profiling = enabled != 0;
+    return 1;
+}
+int musica_profile_reset(musica_ctx* c) {
+    CHECK_CTX(c);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    c->spans_used = 0;
+    memset(c->prof_total_us, 0, sizeof(c->prof_total_us));
+    memset(c->prof_count, 0, sizeof(c->prof_count));
+    return 1;
+}
+int musica_profile_get(musica_ctx* c, musica_kernel_id id, double* mean_us, uint64_t* launches) {
+    CHECK_CTX(c);
+    if ((int)id < 0 || id >= MUSICA_KERNEL_COUNT) return fail("musica_profile_get: bad kernel id %d", (int)id);
+    if (mean_us) *mean_us = c->prof_count[id] ? c->prof_total_us[id] / (double)c->prof_count[id] : 0.0;
+    if (launches) *launches = c->prof_count[id];
+    return 1;
+}
+
+// ---- stand-alone metric kernel ----------------------------------------------------------
+static int reduce_descs(uint32_t side, uint32_t in_pitch, uint32_t out_pitch, LevelDesc* li, LevelDesc* lo) {
+    if (side < 1) return fail("musica_k_reduce: side must be >= 1");
+    const uint32_t so = (side + 1) / 2;
+    if (in_pitch < side || (in_pitch & 3) || out_pitch < so || (out_pitch & 3)) return fail("musica_k_reduce: pitches must be multiples of 4 floats and cover the rows");
+    li->S = (int)side; li->pitch = (int)in_pitch; li->plane = (size_t)in_pitch * side;
+    lo->S = (int)so; lo->pitch = (int)out_pitch; lo->plane = (size_t)out_pitch * so;
+    return 1;
+}
+
+int musica_k_reduce(musica_ctx* c, const float* d_in, uint32_t side, uint32_t in_pitch, float* d_out, uint32_t out_pitch, uint32_t batch) {
+    CHECK_CTX(c);
+    LevelDesc li, lo;
+    if (!reduce_descs(side, in_pitch, out_pitch, &li, &lo)) return 0;
+    launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, pick_rows(c->reduce_rows, 4, li.S, lo.S, (int)batch), c->generic);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e));
+    return 1;
+}
+
+int musica_k_reduce_timed(musica_ctx* c, const float* d_in, uint32_t side, uint32_t in_pitch, float* d_out, uint32_t out_pitch, uint32_t batch,
+                          uint32_t iters, double* mean_us) {
+    CHECK_CTX(c);
+    LevelDesc li, lo;
+    if (!reduce_descs(side, in_pitch, out_pitch, &li, &lo)) return 0;
+    if (iters < 1) iters = 1;
+    const int rpw = pick_rows(c->reduce_rows, 4, li.S, lo.S, (int)batch);
+    hipEvent_t a, b;
+    HIP_OK(hipEventCreate(&a));
+    HIP_OK(hipEventCreate(&b));
+    HIP_OK(hipEventRecord(a, c->stream));
+    for (uint32_t i = 0; i < iters; i++) launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, rpw, c->generic);
+    HIP_OK(hipEventRecord(b, c->stream));
+    HIP_OK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    if (mean_us) *mean_us = (double)ms * 1000.0 / (double)iters;
+    return 1;
+}
+
+void* musica_device_alloc(musica_ctx* c, size_t bytes) {
+    if (!c || hipSetDevice(c->p.device) != hipSuccess) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { fail("musica_device_alloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+void musica_device_free(musica_ctx* c, void* p) {
+    if (!c || !p) return;
+    hipSetDevice(c->p.device);
+    hipStreamSynchronize(c->stream);
+    hipFree(p);
+}
+int musica_memcpy_h2d(musica_ctx* c, void* d_dst, const void* src, size_t bytes) {
+    CHECK_CTX(c);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return 1;
+}
+int musica_memcpy_d2h(musica_ctx* c, void* dst, const void* d_src, size_t bytes) {
+    CHECK_CTX(c);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// musica_io.cpp — the two file formats of the reference's CLI contract (host only, no GPU):
+//   input : test/standalone/main.cpp:54-75 — 256-byte header (ignored) + N*N little-endian uint16,
+//           file size must equal 256 + 2*N*N exactly;
+//   output: stbi_write_bmp(path, w, h, comp = 1, data) as called by saveOutImage
+//           (src/vk_processing.cpp:2636-2642): 24-bpp BI_RGB, gray replicated to B, G, R, rows stored
+//           bottom-up and padded to 4 bytes (dependencies/stb/stb_image_write.h:492-500, :451-476).
+#include <stdint.h>
+#include <stdio.h>
+
+#include <vector>
+
+#include "../../include/musica.h"
+
+extern "C" int musica_read_raw(const char* path, uint32_t image_size, uint16_t* dst) {
+    if (!path || !dst) return 0;
+    FILE* f = fopen(path, "rb");
+    if (!f) return 0;
+    const long offset = 256;
+    const long expected = offset + (long)image_size * image_size * 2;
+    fseek(f, 0, SEEK_END);
+    const long size = ftell(f);
+    if (size != expected) {  // "the image data don't match the actual image size", main.cpp:57-60
+        fclose(f);
+        return 0;
+    }
+    fseek(f, offset, SEEK_SET);
+    std::vector<uint8_t> buf((size_t)image_size * image_size * 2);
+    const size_t got = fread(buf.data(), 1, buf.size(), f);
+    fclose(f);
+    if (got != buf.size()) return 0;
+    const size_t n = (size_t)image_size * image_size;
+    for (size_t i = 0; i < n; i++) dst[i] = (uint16_t)((buf[2 * i + 1] << 8) | buf[2 * i]);  // main.cpp:71-72
+    return 1;
+}
+
+static void le16(uint8_t* p, uint32_t v) { p[0] = (uint8_t)(v & 0xFF); p[1] = (uint8_t)((v >> 8) & 0xFF); }
+static void le32(uint8_t* p, uint32_t v) { le16(p, v & 0xFFFF); le16(p + 2, v >> 16); }
+
+extern "C" int musica_write_bmp_gray(const char* path, uint32_t w, uint32_t h, const uint8_t* data) {
+    if (!path || !data) return 0;
+    FILE* f = fopen(path, "wb");
+    if (!f) return 0;
+    const uint32_t pad = (uint32_t)(-(int32_t)(w * 3)) & 3u;
+    const uint32_t row_bytes = w * 3 + pad;
+    uint8_t hdr[54] = {0};
+    hdr[0] = 'B'; hdr[1] = 'M';
+    le32(hdr + 2, 14 + 40 + row_bytes * h);  // file size
+    le32(hdr + 10, 14 + 40);                 // pixel data offset
+    le32(hdr + 14, 40);                      // BITMAPINFOHEADER
+    le32(hdr + 18, w);
+    le32(hdr + 22, h);
+    le16(hdr + 26, 1);                       // planes
+    le16(hdr + 28, 24);                      // bits per pixel; compression and the rest stay 0
+    bool ok = fwrite(hdr, 1, sizeof(hdr), f) == sizeof(hdr);
+    std::vector<uint8_t> row(row_bytes, 0);
+    for (int64_t j = (int64_t)h - 1; j >= 0 && ok; j--) {
+        const uint8_t* src = data + (size_t)j * w;
+        for (uint32_t i = 0; i < w; i++) row[3 * i] = row[3 * i + 1] = row[3 * i + 2] = src[i];
+        ok = fwrite(row.data(), 1, row_bytes, f) == row_bytes;
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? 1 : 0;
+}

@@ -1,0 +1,88 @@
+// musica-standalone <raw_path> <out_path> [--size N] [--levels L] [--device D] [--debug-dir DIR]
+//
+// Drop-in for the reference's `maverick-standalone.exe <raw_path>.raw <out_path>.bmp`
+// (test/standalone/README.md:3, test/standalone/main.cpp:30-87), which is what the metamorphic
+// harness spawns (test/metamorphic_test/script.py:200-214, check=True on the exit code):
+//   * exactly two positional arguments, else "MAIN ERROR: wrong number of arguments", exit 1;
+//   * input = 256-byte header + 3072*3072 little-endian uint16 (size checked), main.cpp:54-75;
+//   * init(3072) -> execute -> saveOutImage(out), exit 0; any failure prints
+//     "MAIN ERROR: <msg>" to stderr and exits 1 (main.cpp:7-11).
+// Extensions that keep the two-argument form compatible: --size / --levels (also MUSICA_SIZE /
+// MUSICA_LEVELS in the environment), --device, and --debug-dir (the debugProcess() dumps that the
+// reference writes in non-NDEBUG builds, main.cpp:81-83).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "../../include/musica.h"
+
+#define ASSERT_MSG(cond, msg)                        \
+    if (!(cond)) {                                   \
+        fprintf(stderr, "MAIN ERROR: %s\n", msg);    \
+        exit(1);                                     \
+    }
+
+int main(int argc, char* argv[]) {
+    uint32_t imageSize = 3072;  // main.cpp:31
+    uint32_t levels = 0;        // ceil(log2 N), src/vk_processing.cpp:1989
+    int device = 0;
+    const char* debugDir = nullptr;
+    if (const char* e = getenv("MUSICA_SIZE")) imageSize = (uint32_t)atoi(e);
+    if (const char* e = getenv("MUSICA_LEVELS")) levels = (uint32_t)atoi(e);
+
+    for (int i = 0; i < argc; i++) printf("%d = %s\n", i, argv[i]);  // main.cpp:33-35
+
+    std::vector<const char*> pos;
+    for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "--size") && i + 1 < argc) imageSize = (uint32_t)atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--levels") && i + 1 < argc) levels = (uint32_t)atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--debug-dir") && i + 1 < argc) debugDir = argv[++i];
+        else pos.push_back(argv[i]);
+    }
+    ASSERT_MSG(pos.size() == 2, "wrong number of arguments");  // main.cpp:37
+
+    const std::string rawFile = pos[0], outFile = pos[1];
+    printf("raw file %s\n", rawFile.c_str());
+    printf("out file %s\n", outFile.c_str());
+
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    musica_params p;
+    memset(&p, 0, sizeof(p));
+    p.image_size = imageSize;
+    p.levels = levels;
+    p.batch = 1;
+    p.device = device;
+    musica_ctx* ctx = musica_create(&p);
+    ASSERT_MSG(ctx != nullptr, "failed to initialize vk processing");  // main.cpp:51 (message kept)
+
+    std::vector<uint16_t> pixels((size_t)imageSize * imageSize);
+    {
+        FILE* f = fopen(rawFile.c_str(), "rb");
+        ASSERT_MSG(f != nullptr, "failed to load file");  // main.cpp:55
+        fclose(f);
+    }
+    ASSERT_MSG(musica_read_raw(rawFile.c_str(), imageSize, pixels.data()),
+               "the image data don't match the actual image size");  // main.cpp:60
+    const auto t1 = std::chrono::high_resolution_clock::now();
+
+    ASSERT_MSG(musica_execute(ctx, pixels.data()), "processing failed");  // main.cpp:77
+    const auto t2 = std::chrono::high_resolution_clock::now();
+
+    ASSERT_MSG(musica_save_out_image(ctx, 0, outFile.c_str()), "failed to save out image");  // main.cpp:79
+    if (debugDir) ASSERT_MSG(musica_debug_process(ctx, 0, debugDir), "failed to debug process");  // main.cpp:81-83
+    const auto t3 = std::chrono::high_resolution_clock::now();
+
+    auto ms = [](std::chrono::high_resolution_clock::time_point a, std::chrono::high_resolution_clock::time_point b) {
+        return std::chrono::duration<float, std::chrono::milliseconds::period>(b - a).count();
+    };
+    // the reference prints one per-stage timing line per execute (src/vk_processing.cpp:2585-2595)
+    printf("init: %.2f \t exec: %.2f \t save: %.2f \t tot: %.2f \n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t0, t3));
+
+    musica_destroy(ctx);  // main.cpp:85-86
+    return 0;
+}

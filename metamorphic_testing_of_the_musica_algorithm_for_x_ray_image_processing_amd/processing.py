@@ -1,0 +1,428 @@
+"""ctypes mirror of the reference's pipeline object on top of libmusica_hip.so.
+
+`MusicaProcessing` keeps the public surface of `class VulkanProcessing`
+(reference include/vk_processing.h:281-355): init(imageSize), execute(imageData),
+saveOutImage(filePath), debugProcess(), cleanup(), getImageSize() — same argument
+meaning, `bool` results, and an error line on stderr when a call fails. Everything
+else (`batch`, `levels`, getters for intermediates) is the extension surface the
+parity tests and the batch driver use.
+
+There is no CPU fallback: the shared library is HIP-only and every call fails
+loudly when the extension or a GPU is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmusica_hip.so")
+CLI_PATH = os.path.join(_HERE, "musica-standalone")
+
+MAX_POINTS = 256
+NOISE_BINS = 2048
+GRAD_BINS = 1024
+OUT_MARGIN = 10
+
+FLAG_CLAHE = 0x1
+FLAG_NO_GRAPH = 0x2
+FLAG_GENERIC_KERNELS = 0x4
+
+IMG_NORMALIZED, IMG_DOWNSAMPLED, IMG_BANDPASS, IMG_SDEV, IMG_CNR, IMG_EXPAND = 0, 1, 2, 3, 4, 5
+IMG_GRADED, IMG_RELEVANT, IMG_LOWPASS, IMG_EXP_BANDPASS, IMG_SQRT, IMG_CLAHE_GRADED = 6, 7, 8, 9, 10, 11
+STAGE_NORM, STAGE_REDUCE, STAGE_ANALYSIS, STAGE_EXPAND, STAGE_GRADATION = 0, 1, 2, 3, 4
+
+KERNEL_NAMES = ["minmax", "normalize", "reduce_l0", "reduce_rest", "band_l0", "band_rest", "sdev_hist", "curves",
+                "cnr", "expand_l0", "expand_rest", "grad_hist", "grad_curve", "grad_apply"]
+KERNEL_ID = {n: i for i, n in enumerate(KERNEL_NAMES)}
+
+
+class Params(C.Structure):
+    _fields_ = [("image_size", C.c_uint32), ("levels", C.c_uint32), ("batch", C.c_uint32),
+                ("device", C.c_int32), ("flags", C.c_uint32)]
+
+
+class HistMaxPoint(C.Structure):
+    _fields_ = [("maxValue", C.c_uint32), ("maxBin", C.c_uint32)]
+
+
+class ContrastParams(C.Structure):
+    _fields_ = [("lowContrastFactor", C.c_float), ("highContrastFactor", C.c_float)]
+
+
+class Point(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float)]
+
+
+class ContrastCurve(C.Structure):
+    _fields_ = [("points", Point * MAX_POINTS), ("pointsCount", C.c_uint32)]
+
+    def as_array(self):
+        return np.array([(self.points[i].x, self.points[i].y) for i in range(self.pointsCount)], dtype=np.float32)
+
+
+class NrParams(C.Structure):
+    _fields_ = [("lowCnr", C.c_float), ("lowFactor", C.c_float), ("highCnr", C.c_float), ("highFactor", C.c_float)]
+
+
+class GradCurve(C.Structure):
+    _fields_ = [("points", Point * MAX_POINTS), ("pointsCount", C.c_uint32),
+                ("t0", C.c_float), ("ta", C.c_float), ("t1", C.c_float)]
+
+    def as_array(self):
+        return np.array([(self.points[i].x, self.points[i].y) for i in range(self.pointsCount)], dtype=np.float32)
+
+
+class Stats(C.Structure):
+    _fields_ = [("image_id", C.c_uint32), ("min_sqrt", C.c_float), ("max_sqrt", C.c_float),
+                ("noise_max_bin", C.c_uint32 * 4), ("noise_max_value", C.c_uint32 * 4),
+                ("grad_max_bin", C.c_uint32), ("grad_max_value", C.c_uint32),
+                ("mean_cnr", C.c_float), ("t0", C.c_float), ("ta", C.c_float), ("t1", C.c_float)]
+
+    FLOAT_FIELDS = ("min_sqrt", "max_sqrt", "mean_cnr", "t0", "ta", "t1")
+
+    def as_row(self):
+        """Fixed-size float64 row for the RCCL all-gather of the batch driver (13 values)."""
+        return [float(self.image_id), self.min_sqrt, self.max_sqrt] + [float(v) for v in self.noise_max_bin] + \
+               [float(self.grad_max_bin), self.mean_cnr, self.t0, self.ta, self.t1, float(self.grad_max_value)]
+
+
+# Every symbol include/musica.h declares: (restype, argtypes). tests/test_abi.py checks the
+# shared object exports exactly these.
+_VP = C.c_void_p
+_U8P, _U16P, _U32P, _F32P = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+ABI = {
+    "musica_create": (_VP, [C.POINTER(Params)]),
+    "musica_destroy": (None, [_VP]),
+    "musica_get_image_size": (C.c_uint32, [_VP]),
+    "musica_get_levels": (C.c_uint32, [_VP]),
+    "musica_get_batch": (C.c_uint32, [_VP]),
+    "musica_get_level_size": (C.c_uint32, [_VP, C.c_uint32]),
+    "musica_execute": (C.c_int, [_VP, _U16P]),
+    "musica_execute_device": (C.c_int, [_VP, _VP]),
+    "musica_upload": (C.c_int, [_VP, _U16P]),
+    "musica_input_device_ptr": (_VP, [_VP]),
+    "musica_sync": (C.c_int, [_VP]),
+    "musica_get_graded": (C.c_int, [_VP, _F32P]),
+    "musica_save_out_image": (C.c_int, [_VP, C.c_uint32, C.c_char_p]),
+    "musica_get_out_pixels": (C.c_int, [_VP, C.c_uint32, _U8P]),
+    "musica_get_image": (C.c_int, [_VP, C.c_uint32, C.c_int, C.c_uint32, _F32P]),
+    "musica_image_side": (C.c_uint32, [_VP, C.c_int, C.c_uint32]),
+    "musica_get_noise_hist": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _U32P]),
+    "musica_get_grad_hist": (C.c_int, [_VP, C.c_uint32, _U32P]),
+    "musica_get_noise_hist_max": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.POINTER(HistMaxPoint)]),
+    "musica_get_grad_hist_max": (C.c_int, [_VP, C.c_uint32, C.POINTER(HistMaxPoint)]),
+    "musica_get_contrast_curve": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.POINTER(ContrastCurve)]),
+    "musica_get_grad_curve": (C.c_int, [_VP, C.c_uint32, C.POINTER(GradCurve)]),
+    "musica_get_contrast_params": (C.c_int, [_VP, C.c_uint32, C.POINTER(ContrastParams)]),
+    "musica_get_nr_params": (C.c_int, [_VP, C.c_uint32, C.POINTER(NrParams)]),
+    "musica_get_minmax": (C.c_int, [_VP, C.c_uint32, _F32P, _F32P]),
+    "musica_get_stats": (C.c_int, [_VP, C.c_uint32, C.POINTER(Stats)]),
+    "musica_get_clahe_hist": (C.c_int, [_VP, C.c_uint32, _U32P]),
+    "musica_get_clahe_curves": (C.c_int, [_VP, C.c_uint32, C.POINTER(Point)]),
+    "musica_debug_process": (C.c_int, [_VP, C.c_uint32, C.c_char_p]),
+    "musica_debug_set_image": (C.c_int, [_VP, C.c_uint32, C.c_int, C.c_uint32, _F32P]),
+    "musica_debug_run_stage": (C.c_int, [_VP, C.c_int]),
+    "musica_profile_enable": (C.c_int, [_VP, C.c_int]),
+    "musica_profile_reset": (C.c_int, [_VP]),
+    "musica_profile_get": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "musica_k_reduce": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32]),
+    "musica_k_reduce_timed": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+    "musica_device_alloc": (_VP, [_VP, C.c_size_t]),
+    "musica_device_free": (None, [_VP, _VP]),
+    "musica_memcpy_h2d": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    "musica_memcpy_d2h": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    "musica_read_raw": (C.c_int, [C.c_char_p, C.c_uint32, _U16P]),
+    "musica_write_bmp_gray": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _U8P]),
+    "musica_last_error": (C.c_char_p, []),
+    "musica_abi_version": (C.c_uint32, []),
+    "musica_device_count": (C.c_int, []),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load libmusica_hip.so (built in-tree by build.py). Raises if it is missing: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libmusica_hip.so is not built: run `python -m %s.build` (hipcc, gfx950)" % __package__)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return (load_library().musica_last_error() or b"").decode("utf-8", "replace")
+
+
+def device_count():
+    return load_library().musica_device_count()
+
+
+def _f32p(a):
+    return a.ctypes.data_as(_F32P)
+
+
+class MusicaProcessing:
+    """Drop-in for the reference's VulkanProcessing (one HIP stream on one device per object)."""
+
+    def __init__(self, device=0):
+        # reference: VulkanProcessing(VulkanState*) — the state object selected the physical device
+        self._lib = load_library()
+        self._device = int(device)
+        self._h = None
+        self.imageSize = 0
+        self.pyramidLevels = 0
+        self.batch = 1
+
+    # ---- the reference's interface -------------------------------------------------
+    def init(self, imageSize, outImageViews=None, levels=0, batch=1, flags=0):
+        """bool init(uint32_t imageSize, std::vector<VkImageView>*) — src/vk_processing.cpp:1984-2020."""
+        if self._h:
+            self.cleanup()
+        p = Params(int(imageSize), int(levels), int(batch), self._device, int(flags))
+        h = self._lib.musica_create(C.byref(p))
+        if not h:
+            return False
+        self._h = h
+        self.imageSize = self._lib.musica_get_image_size(h)
+        self.pyramidLevels = self._lib.musica_get_levels(h)
+        self.batch = self._lib.musica_get_batch(h)
+        return True
+
+    def execute(self, imageData):
+        """bool execute(const uint16_t* imageData) — src/vk_processing.cpp:2104-2601 (synchronous)."""
+        px = self._pixels(imageData)
+        return self._lib.musica_execute(self._h, px.ctypes.data_as(_U16P)) == 1
+
+    def saveOutImage(self, filePath, image_index=0):
+        """bool saveOutImage(std::string filePath) — src/vk_processing.cpp:2603-2645."""
+        return self._lib.musica_save_out_image(self._h, image_index, os.fsencode(filePath)) == 1
+
+    def debugProcess(self, directory=".", image_index=0):
+        """bool debugProcess() — src/vk_processing.cpp:2661-2809 (the reference writes into the cwd)."""
+        return self._lib.musica_debug_process(self._h, image_index, os.fsencode(directory)) == 1
+
+    def cleanup(self):
+        """bool cleanup() — src/vk_processing.cpp:2647-2651."""
+        if self._h:
+            self._lib.musica_destroy(self._h)
+            self._h = None
+        return True
+
+    def getImageSize(self):
+        return self.imageSize
+
+    # ---- extension surface ------------------------------------------------------------
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass
+
+    def _pixels(self, imageData):
+        px = np.ascontiguousarray(imageData, dtype=np.uint16)
+        need = self.batch * self.imageSize * self.imageSize
+        if px.size != need:
+            raise ValueError("expected %d pixels (batch %d x %d x %d), got %d" % (need, self.batch, self.imageSize, self.imageSize, px.size))
+        return px
+
+    def _ok(self, rc, what):
+        if rc != 1:
+            raise RuntimeError("%s failed: %s" % (what, last_error()))
+
+    def level_size(self, level):
+        return self._lib.musica_get_level_size(self._h, level)
+
+    def upload(self, imageData):
+        px = self._pixels(imageData)
+        self._ok(self._lib.musica_upload(self._h, px.ctypes.data_as(_U16P)), "musica_upload")
+
+    def input_device_ptr(self):
+        return self._lib.musica_input_device_ptr(self._h)
+
+    def execute_device(self, d_pixels=None):
+        """Enqueue the pipeline on input already resident in HBM (default: the uploaded buffer)."""
+        ptr = d_pixels if d_pixels is not None else self.input_device_ptr()
+        return self._lib.musica_execute_device(self._h, ptr) == 1
+
+    def sync(self):
+        self._ok(self._lib.musica_sync(self._h), "musica_sync")
+
+    def graded(self):
+        n = self.imageSize
+        out = np.empty((self.batch, n, n), dtype=np.float32)
+        self._ok(self._lib.musica_get_graded(self._h, _f32p(out)), "musica_get_graded")
+        return out
+
+    def out_pixels(self, image_index=0):
+        n = self.imageSize - 2 * OUT_MARGIN
+        out = np.empty((n, n), dtype=np.uint8)
+        self._ok(self._lib.musica_get_out_pixels(self._h, image_index, out.ctypes.data_as(_U8P)), "musica_get_out_pixels")
+        return out
+
+    def image(self, kind, level=0, image_index=0):
+        s = self._lib.musica_image_side(self._h, kind, level)
+        if s == 0:
+            raise KeyError("no image kind=%d level=%d" % (kind, level))
+        out = np.empty((s, s), dtype=np.float32)
+        self._ok(self._lib.musica_get_image(self._h, image_index, kind, level, _f32p(out)), "musica_get_image")
+        return out
+
+    def set_image(self, kind, level, arr, image_index=0):
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        self._ok(self._lib.musica_debug_set_image(self._h, image_index, kind, level, _f32p(a)), "musica_debug_set_image")
+
+    def run_stage(self, stage):
+        self._ok(self._lib.musica_debug_run_stage(self._h, stage), "musica_debug_run_stage")
+
+    def noise_hist(self, level, image_index=0):
+        out = np.empty(NOISE_BINS, dtype=np.uint32)
+        self._ok(self._lib.musica_get_noise_hist(self._h, image_index, level, out.ctypes.data_as(_U32P)), "musica_get_noise_hist")
+        return out
+
+    def grad_hist(self, image_index=0):
+        out = np.empty(GRAD_BINS, dtype=np.uint32)
+        self._ok(self._lib.musica_get_grad_hist(self._h, image_index, out.ctypes.data_as(_U32P)), "musica_get_grad_hist")
+        return out
+
+    def noise_hist_max(self, level, image_index=0):
+        p = HistMaxPoint()
+        self._ok(self._lib.musica_get_noise_hist_max(self._h, image_index, level, C.byref(p)), "musica_get_noise_hist_max")
+        return (p.maxValue, p.maxBin)
+
+    def grad_hist_max(self, image_index=0):
+        p = HistMaxPoint()
+        self._ok(self._lib.musica_get_grad_hist_max(self._h, image_index, C.byref(p)), "musica_get_grad_hist_max")
+        return (p.maxValue, p.maxBin)
+
+    def contrast_curve(self, level, image_index=0):
+        c = ContrastCurve()
+        self._ok(self._lib.musica_get_contrast_curve(self._h, image_index, level, C.byref(c)), "musica_get_contrast_curve")
+        return c.as_array()
+
+    def grad_curve(self, image_index=0):
+        c = GradCurve()
+        self._ok(self._lib.musica_get_grad_curve(self._h, image_index, C.byref(c)), "musica_get_grad_curve")
+        return c.as_array(), (c.t0, c.ta, c.t1)
+
+    def contrast_params(self, level):
+        p = ContrastParams()
+        self._ok(self._lib.musica_get_contrast_params(self._h, level, C.byref(p)), "musica_get_contrast_params")
+        return (p.lowContrastFactor, p.highContrastFactor)
+
+    def nr_params(self, level):
+        p = NrParams()
+        self._ok(self._lib.musica_get_nr_params(self._h, level, C.byref(p)), "musica_get_nr_params")
+        return (p.lowCnr, p.lowFactor, p.highCnr, p.highFactor)
+
+    def minmax(self, image_index=0):
+        a, b = C.c_float(), C.c_float()
+        self._ok(self._lib.musica_get_minmax(self._h, image_index, C.byref(a), C.byref(b)), "musica_get_minmax")
+        return a.value, b.value
+
+    def stats(self, image_index=0):
+        s = Stats()
+        self._ok(self._lib.musica_get_stats(self._h, image_index, C.byref(s)), "musica_get_stats")
+        return s
+
+    def clahe_hist(self, image_index=0):
+        out = np.empty((4, 4, 256), dtype=np.uint32)
+        self._ok(self._lib.musica_get_clahe_hist(self._h, image_index, out.ctypes.data_as(_U32P)), "musica_get_clahe_hist")
+        return out
+
+    def clahe_curves(self, image_index=0):
+        out = np.empty((4, 4, 256, 2), dtype=np.float32)
+        self._ok(self._lib.musica_get_clahe_curves(self._h, image_index, C.cast(out.ctypes.data, C.POINTER(Point))), "musica_get_clahe_curves")
+        return out
+
+    # ---- profiling ----------------------------------------------------------------------
+    def profile_enable(self, enabled=True):
+        self._ok(self._lib.musica_profile_enable(self._h, 1 if enabled else 0), "musica_profile_enable")
+
+    def profile_reset(self):
+        self._ok(self._lib.musica_profile_reset(self._h), "musica_profile_reset")
+
+    def profile(self):
+        """{kernel name: (mean microseconds, launches)} since the last reset."""
+        out = {}
+        for name, kid in KERNEL_ID.items():
+            us, n = C.c_double(), C.c_uint64()
+            self._ok(self._lib.musica_profile_get(self._h, kid, C.byref(us), C.byref(n)), "musica_profile_get")
+            out[name] = (us.value, n.value)
+        return out
+
+    # ---- the metric kernel on caller-owned device buffers ---------------------------------
+    def device_alloc(self, nbytes):
+        p = self._lib.musica_device_alloc(self._h, nbytes)
+        if not p:
+            raise MemoryError(last_error())
+        return p
+
+    def device_free(self, ptr):
+        self._lib.musica_device_free(self._h, ptr)
+
+    def h2d(self, d_dst, arr):
+        a = np.ascontiguousarray(arr)
+        self._ok(self._lib.musica_memcpy_h2d(self._h, d_dst, a.ctypes.data, a.nbytes), "musica_memcpy_h2d")
+
+    def d2h(self, arr, d_src):
+        self._ok(self._lib.musica_memcpy_d2h(self._h, arr.ctypes.data, d_src, arr.nbytes), "musica_memcpy_d2h")
+
+    def k_reduce_host(self, images):
+        """Fused smooth + downsample of a (batch, S, S) f32 array staged through device buffers."""
+        a = np.ascontiguousarray(images, dtype=np.float32)
+        if a.ndim == 2:
+            a = a[None]
+        b, s, _ = a.shape
+        pitch, so = (s + 3) & ~3, (s + 1) // 2
+        opitch = (so + 3) & ~3
+        padded = np.zeros((b, s, pitch), dtype=np.float32)
+        padded[:, :, :s] = a
+        d_in, d_out = self.device_alloc(padded.nbytes), self.device_alloc(b * so * opitch * 4)
+        try:
+            self.h2d(d_in, padded)
+            self._ok(self._lib.musica_k_reduce(self._h, d_in, s, pitch, d_out, opitch, b), "musica_k_reduce")
+            out = np.empty((b, so, opitch), dtype=np.float32)
+            self.d2h(out, d_out)
+        finally:
+            self.device_free(d_in)
+            self.device_free(d_out)
+        return out[:, :, :so].copy()
+
+    def k_reduce_timed(self, side, batch=1, iters=50, seed=0):
+        """Mean microseconds per launch of the metric kernel on a random side x side image in HBM."""
+        pitch, so = (side + 3) & ~3, (side + 1) // 2
+        opitch = (so + 3) & ~3
+        rng = np.random.default_rng(seed)
+        src = rng.random((batch, side, pitch), dtype=np.float32)
+        d_in, d_out = self.device_alloc(src.nbytes), self.device_alloc(batch * so * opitch * 4)
+        try:
+            self.h2d(d_in, src)
+            us = C.c_double()
+            self._ok(self._lib.musica_k_reduce_timed(self._h, d_in, side, pitch, d_out, opitch, batch, 3, C.byref(us)), "warmup")
+            self._ok(self._lib.musica_k_reduce_timed(self._h, d_in, side, pitch, d_out, opitch, batch, iters, C.byref(us)), "musica_k_reduce_timed")
+        finally:
+            self.device_free(d_in)
+            self.device_free(d_out)
+        return us.value
+
+
+def read_raw(path, image_size):
+    """The raw reader of test/standalone/main.cpp:54-75; None when the file size does not match."""
+    out = np.empty((image_size, image_size), dtype=np.uint16)
+    ok = load_library().musica_read_raw(os.fsencode(path), image_size, out.ctypes.data_as(_U16P))
+    return out if ok == 1 else None
+
+
+def write_bmp_gray(path, data):
+    d = np.ascontiguousarray(data, dtype=np.uint8)
+    h, w = d.shape
+    return load_library().musica_write_bmp_gray(os.fsencode(path), w, h, d.ctypes.data_as(_U8P)) == 1

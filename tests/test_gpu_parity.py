@@ -1,0 +1,306 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (stated here so the numbers live next to the assertions):
+  * HIP vs oracle in MUSICA_ORDER_FAST (the arithmetic order the kernels implement): every f32
+    image BIT-IDENTICAL (compared as float arrays, so -0 == +0), every histogram / argmax / curve
+    point / window scalar EXACTLY equal, the final 8-bit pixels identical;
+  * HIP vs oracle in MUSICA_ORDER_REFERENCE (literal 25-tap accumulation of the shaders): pyramid
+    images within 4e-6 absolute on [0, 1]-scaled data, noise-histogram argmax within 1 bin,
+    final 8-bit image: at most 0.1 % of pixels differ (getY's x > 1 -> 0 discontinuity and bin
+    flips at 1e-7-level differences are inherent to the reference's semantics).
+PARITY UNPINNED note: the oracle itself is pinned only by the analytic KATs in test_oracle_kat.py
+(no golden vectors exist in the reference for this path).
+"""
+import numpy as np
+import pytest
+
+from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd import processing as mp
+from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.phantom import phantom
+
+pytestmark = pytest.mark.gpu
+
+
+def _proc(n, levels=0, batch=1, flags=0):
+    p = mp.MusicaProcessing()
+    assert p.init(n, levels=levels, batch=batch, flags=flags), mp.last_error()
+    return p
+
+
+def _same(a, b, what):
+    assert a.shape == b.shape, what
+    eq = (a == b) | (np.isnan(a) & np.isnan(b))
+    if not eq.all():
+        bad = np.argwhere(~eq)
+        y, x = bad[0][-2], bad[0][-1]
+        raise AssertionError("%s: %d / %d texels differ, first at (x=%d, y=%d): hip=%r oracle=%r, max abs diff %g"
+                             % (what, len(bad), a.size, x, y, a[tuple(bad[0])], b[tuple(bad[0])], np.nanmax(np.abs(a - b))))
+
+
+def _compare_all(p, o, ob, idx=0, tag=""):
+    L = o.levels
+    _same(p.image(mp.IMG_NORMALIZED, 0, idx), o.image(ob.IMG_NORMALIZED), tag + "normalized")
+    assert p.minmax(idx) == o.minmax()
+    for i in range(L):
+        _same(p.image(mp.IMG_DOWNSAMPLED, i, idx), o.image(ob.IMG_DOWNSAMPLED, i), tag + "downsampled[%d]" % i)
+        _same(p.image(mp.IMG_BANDPASS, i, idx), o.image(ob.IMG_BANDPASS, i), tag + "bandpass[%d]" % i)
+    for i in range(4):
+        _same(p.image(mp.IMG_SDEV, i, idx), o.image(ob.IMG_SDEV, i), tag + "sdev[%d]" % i)
+        assert np.array_equal(p.noise_hist(i, idx), o.noise_hist(i)), tag + "noise_hist[%d]" % i
+        assert p.noise_hist_max(i, idx) == o.noise_hist_max(i), tag + "noise_hist_max[%d]" % i
+    for i in range(L):
+        assert np.array_equal(p.contrast_curve(i, idx), o.contrast_curve(i)), tag + "contrast_curve[%d]" % i
+        assert p.contrast_params(i) == o.contrast_params(i)
+    for i in range(3):
+        assert p.nr_params(i) == o.nr_params(i)
+    _same(p.image(mp.IMG_CNR, 3, idx), o.image(ob.IMG_CNR, 3), tag + "cnr")
+    for i in reversed(range(L)):
+        _same(p.image(mp.IMG_EXPAND, i, idx), o.image(ob.IMG_EXPAND, i), tag + "expand[%d]" % i)
+    assert np.array_equal(p.grad_hist(idx), o.grad_hist()), tag + "grad_hist"
+    assert p.grad_hist_max(idx) == o.grad_hist_max()
+    gc, gw = p.grad_curve(idx)
+    oc, ow = o.grad_curve()
+    assert np.array_equal(gc, oc) and gw == ow, tag + "grad_curve"
+    _same(p.image(mp.IMG_GRADED, 0, idx), o.image(ob.IMG_GRADED), tag + "graded")
+    assert np.array_equal(p.out_pixels(idx), o.out_pixels()), tag + "out pixels"
+    # on-demand (debugProcess) images
+    _same(p.image(mp.IMG_RELEVANT, 0, idx), o.image(ob.IMG_RELEVANT), tag + "relevant")
+    _same(p.image(mp.IMG_SQRT, 0, idx), o.image(ob.IMG_SQRT), tag + "sqrt")
+    for i in (0, L - 1):
+        _same(p.image(mp.IMG_LOWPASS, i, idx), o.image(ob.IMG_LOWPASS, i), tag + "lowpass[%d]" % i)
+        _same(p.image(mp.IMG_EXP_BANDPASS, i, idx), o.image(ob.IMG_EXP_BANDPASS, i), tag + "exp_bandpass[%d]" % i)
+    hs, os_ = p.stats(idx), o.stats()
+    assert list(hs.noise_max_bin) == list(os_.noise_max_bin) and hs.grad_max_bin == os_.grad_max_bin
+    assert (hs.t0, hs.ta, hs.t1) == (os_.t0, os_.ta, os_.t1)
+    assert abs(hs.mean_cnr - os_.mean_cnr) <= 1e-5 * max(1.0, abs(os_.mean_cnr))   # f64 sums in a different order
+
+
+# configs[0] of BASELINE.json (512, L = 4), the reference's level rule (L = ceil(log2 N)) down to
+# 2x2 / 1x1 levels, sizes that are not multiples of 8 / 4 / 2, a power of 8 (exact min chain) and
+# the 2048 / L6 case of configs[1].
+CASES = [(512, 4, 1), (512, 0, 2), (256, 0, 3), (200, 5, 4), (1000, 6, 5), (333, 0, 6), (1024, 6, 7), (2048, 6, 8), (1792, 0, 9)]
+
+
+@pytest.mark.parametrize("n,levels,seed", CASES)
+def test_pipeline_bit_exact_vs_fast_oracle(ob, n, levels, seed):
+    px = phantom(n, seed)
+    o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px)
+    p = _proc(n, levels)
+    assert p.execute(px), mp.last_error()
+    assert p.pyramidLevels == o.levels
+    _compare_all(p, o, ob)
+    p.cleanup()
+
+
+def test_twelve_bit_input_and_second_execute_is_idempotent(ob):
+    n = 768
+    px = phantom(n, 21, bits=12)
+    assert px.max() <= 4095
+    o = ob.Oracle(n, 6, ob.ORDER_FAST).execute(px)
+    p = _proc(n, 6)
+    assert p.execute(px)
+    _compare_all(p, o, ob)
+    first = p.graded().copy()
+    assert p.execute(px)                     # histograms are cleared per execute (src/vk_processing.cpp:2153-2162)
+    assert np.array_equal(first, p.graded())
+    _compare_all(p, o, ob)
+    p.cleanup()
+
+
+def test_batch_of_independent_images(ob):
+    n, levels, b = 512, 5, 3
+    px = np.stack([phantom(n, 100 + k) for k in range(b)])
+    p = _proc(n, levels, batch=b)
+    assert p.execute(px)
+    for k in range(b):
+        o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[k])
+        _compare_all(p, o, ob, idx=k, tag="image %d: " % k)
+    p.cleanup()
+
+
+def test_resident_input_entry_point(ob):
+    n = 512
+    px = phantom(n, 33)
+    p = _proc(n, 5)
+    p.upload(px)
+    assert p.execute_device()
+    p.sync()
+    o = ob.Oracle(n, 5, ob.ORDER_FAST).execute(px)
+    _same(p.graded()[0], o.image(ob.IMG_GRADED), "graded (resident input)")
+    p.cleanup()
+
+
+@pytest.mark.parametrize("n,levels", [(512, 5), (1000, 6), (264, 0)])
+def test_streaming_kernels_equal_generic_kernels(n, levels):
+    px = phantom(n, 77)
+    a, b = _proc(n, levels), _proc(n, levels, flags=mp.FLAG_GENERIC_KERNELS)
+    assert a.execute(px) and b.execute(px)
+    for i in range(a.pyramidLevels):
+        _same(a.image(mp.IMG_DOWNSAMPLED, i), b.image(mp.IMG_DOWNSAMPLED, i), "downsampled[%d]" % i)
+        _same(a.image(mp.IMG_BANDPASS, i), b.image(mp.IMG_BANDPASS, i), "bandpass[%d]" % i)
+        _same(a.image(mp.IMG_EXPAND, i), b.image(mp.IMG_EXPAND, i), "expand[%d]" % i)
+    _same(a.graded(), b.graded(), "graded")
+    a.cleanup()
+    b.cleanup()
+
+
+@pytest.mark.parametrize("side", [8, 16, 24, 64, 100, 257, 512, 520, 1024, 1032, 3, 2, 1, 5, 7, 12])
+def test_metric_kernel_vs_oracle(ob, side):
+    rng = np.random.default_rng(side)
+    img = rng.random((2, side, side), dtype=np.float32)
+    p = _proc(64, 4)
+    got = p.k_reduce_host(img)
+    for k in range(2):
+        expect = ob.k_downsample(ob.k_smooth(img[k], ob.ORDER_FAST))
+        _same(got[k], expect, "smooth+downsample side %d image %d" % (side, k))
+        literal = ob.k_downsample(ob.k_smooth(img[k], ob.ORDER_REFERENCE))
+        assert np.abs(got[k] - literal).max() <= 4e-7     # 25 taps, values in [0, 1]
+    p.cleanup()
+
+
+def test_metric_kernel_properties_full_size():
+    # size-independent properties at BASELINE's 4096 x 4096: a constant stays constant (sum w = 1),
+    # and the operator is linear: R(a + b) ~= R(a) + R(b)
+    side = 4096
+    p = _proc(64, 4)
+    const = np.full((1, side, side), 0.75, dtype=np.float32)
+    out = p.k_reduce_host(const)
+    assert out.shape == (1, 2048, 2048)
+    assert np.abs(out - 0.75).max() <= 2e-7
+    rng = np.random.default_rng(4096)
+    a = rng.random((1, side, side), dtype=np.float32)
+    b = rng.random((1, side, side), dtype=np.float32)
+    ra, rb, rab = p.k_reduce_host(a), p.k_reduce_host(b), p.k_reduce_host(a + b)
+    assert np.abs(rab - (ra + rb)).max() <= 1e-6
+    p.cleanup()
+
+
+@pytest.mark.parametrize("n,levels,seed", [(512, 4, 1), (1024, 6, 7)])
+def test_pipeline_close_to_literal_oracle(ob, n, levels, seed):
+    px = phantom(n, seed)
+    o = ob.Oracle(n, levels, ob.ORDER_REFERENCE).execute(px)
+    p = _proc(n, levels)
+    assert p.execute(px)
+    _same(p.image(mp.IMG_NORMALIZED), o.image(ob.IMG_NORMALIZED), "normalized")
+    for i in range(o.levels):
+        assert np.abs(p.image(mp.IMG_DOWNSAMPLED, i) - o.image(ob.IMG_DOWNSAMPLED, i)).max() <= 4e-7
+        assert np.abs(p.image(mp.IMG_BANDPASS, i) - o.image(ob.IMG_BANDPASS, i)).max() <= 1e-6
+    for i in range(4):
+        assert np.abs(p.image(mp.IMG_SDEV, i) - o.image(ob.IMG_SDEV, i)).max() <= 1e-6
+        assert abs(p.noise_hist_max(i)[1] - o.noise_hist_max(i)[1]) <= 1
+        assert np.abs(p.noise_hist(i).astype(np.int64) - o.noise_hist(i).astype(np.int64)).sum() <= 0.01 * o.noise_hist(i).sum() + 4
+    if all(p.noise_hist_max(i)[1] == o.noise_hist_max(i)[1] for i in range(4)):
+        assert np.abs(p.image(mp.IMG_EXPAND, 0) - o.image(ob.IMG_EXPAND, 0)).max() <= 4e-6
+        diff = p.out_pixels().astype(np.int32) != o.out_pixels().astype(np.int32)
+        assert diff.mean() <= 1e-3
+    p.cleanup()
+
+
+def test_analysis_stage_exact_given_identical_band(ob):
+    # "bit-exact for the histogram/index reductions ... given identical f32 input": feed the SAME band
+    # images (from the literal-order oracle) to both sides and run only the analysis stage.
+    n, levels = 1024, 6
+    px = phantom(n, 3)
+    lit = ob.Oracle(n, levels, ob.ORDER_REFERENCE).execute(px)
+    o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px)
+    p = _proc(n, levels)
+    assert p.execute(px)
+    for i in range(levels):
+        band = lit.image(ob.IMG_BANDPASS, i)
+        p.set_image(mp.IMG_BANDPASS, i, band)
+        o.set_image(ob.IMG_BANDPASS, i, band)
+    p.run_stage(mp.STAGE_ANALYSIS)
+    o.run_stage(ob.STAGE_ANALYSIS)
+    for i in range(4):
+        _same(p.image(mp.IMG_SDEV, i), o.image(ob.IMG_SDEV, i), "sdev[%d]" % i)
+        assert np.array_equal(p.noise_hist(i), o.noise_hist(i))
+        assert p.noise_hist_max(i) == o.noise_hist_max(i)
+        assert np.array_equal(p.contrast_curve(i), o.contrast_curve(i))
+    _same(p.image(mp.IMG_CNR, 3), o.image(ob.IMG_CNR, 3), "cnr")
+    p.cleanup()
+
+
+def test_gradation_stage_edge_cases(ob):
+    # zeros inside the reconstruction (`return` semantics of gradation_histogram.comp:24), values > 1
+    # (bins dropped, getY -> 0), NaN, and a non-monotone tone curve (t1 < ts) that forces the literal
+    # first-match scan instead of the binary search.
+    n, levels = 512, 5
+    px = phantom(n, 9)
+    o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px)
+    p = _proc(n, levels)
+    assert p.execute(px)
+    rec = o.image(ob.IMG_EXPAND, 0).copy()
+    rng = np.random.default_rng(0)
+    ys, xs = rng.integers(0, n, 200), rng.integers(0, n, 200)
+    rec[ys[:120], xs[:120]] = 0.0
+    rec[ys[120:160], xs[120:160]] = 1.5
+    rec[ys[160:180], xs[160:180]] = np.nan
+    rec[ys[180:], xs[180:]] = -0.25
+    # squeeze the relevant part of the histogram into a narrow range so that t1 < ts
+    rec[150:360, 150:360] = 0.3 + 0.02 * rng.random((210, 210), dtype=np.float32)
+    p.set_image(mp.IMG_EXPAND, 0, rec)
+    o.set_image(ob.IMG_EXPAND, 0, rec)
+    p.run_stage(mp.STAGE_GRADATION)
+    o.run_stage(ob.STAGE_GRADATION)
+    assert np.array_equal(p.grad_hist(), o.grad_hist())
+    gc, gw = p.grad_curve()
+    oc, ow = o.grad_curve()
+    assert np.array_equal(gc, oc) and gw == ow
+    _same(p.image(mp.IMG_GRADED), o.image(ob.IMG_GRADED), "graded")
+
+
+def test_clahe_gradation(ob):
+    n, levels = 512, 5
+    px = phantom(n, 12)
+    o = ob.Oracle(n, levels, ob.ORDER_FAST, ob.FLAG_CLAHE).execute(px)
+    p = _proc(n, levels, flags=mp.FLAG_CLAHE)
+    assert p.execute(px)
+    assert np.array_equal(p.clahe_hist(), o.clahe_hist())
+    a, b = p.clahe_curves(), o.clahe_curves()
+    assert ((a == b) | (np.isnan(a) & np.isnan(b))).all()
+    _same(p.image(mp.IMG_CLAHE_GRADED), o.image(ob.IMG_CLAHE_GRADED), "clahe graded")
+    _same(p.image(mp.IMG_GRADED), o.image(ob.IMG_GRADED), "graded")      # the old gradation still runs (.cpp:2491-2518)
+    p.cleanup()
+
+
+def test_save_out_image_and_debug_process(ob, tmp_path):
+    n, levels = 512, 5
+    px = phantom(n, 41)
+    o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px)
+    p = _proc(n, levels)
+    assert p.execute(px)
+    a, b = tmp_path / "hip.bmp", tmp_path / "oracle.bmp"
+    assert p.saveOutImage(str(a))
+    o.save_out_image(str(b))
+    assert a.read_bytes() == b.read_bytes()
+    assert len(a.read_bytes()) == 54 + (n - 20) * ((n - 20) * 3)
+    d = tmp_path / "dump"
+    d.mkdir()
+    assert p.debugProcess(str(d))
+    names = {f.name for f in d.iterdir()}
+    for want in ["norm.bmp", "sdev.bmp", "cnr.bmp", "relevant.bmp", "graded.bmp", "noise_hist.csv", "grad_hist.csv", "grad_curve.csv"] + \
+                ["red_bandpass_%d.bmp" % i for i in range(levels)] + ["red_lowpass_%d.bmp" % i for i in range(levels)] + \
+                ["exp_bandpass_%d.bmp" % i for i in range(levels)] + ["exp_lowpass_%d.bmp" % i for i in range(levels)]:
+        assert want in names, want
+    # graded.bmp is the un-cropped 8-bit image (VulkanState::downloadAndSaveImage, src/vk_state.cpp:809-855)
+    raw = (d / "graded.bmp").read_bytes()
+    assert int.from_bytes(raw[18:22], "little") == n
+    p.cleanup()
+
+
+def test_cli_drop_in(ob, tmp_path):
+    import subprocess
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.phantom import write_raw
+    n = 512
+    px = phantom(n, 55)
+    raw, out = tmp_path / "image.raw", tmp_path / "out.bmp"
+    write_raw(str(raw), px)
+    r = subprocess.run([mp.CLI_PATH, str(raw), str(out), "--size", str(n)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "raw file" in r.stdout and "tot:" in r.stdout
+    o = ob.Oracle(n, 0, ob.ORDER_FAST).execute(px)
+    ref = tmp_path / "oracle.bmp"
+    o.save_out_image(str(ref))
+    assert out.read_bytes() == ref.read_bytes()
+    # wrong file size -> MAIN ERROR, exit code 1 (main.cpp:57-60)
+    r = subprocess.run([mp.CLI_PATH, str(raw), str(out), "--size", "256"], capture_output=True, text=True)
+    assert r.returncode == 1 and "MAIN ERROR: the image data don't match the actual image size" in r.stderr
