@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py — full-pipeline MUSICA throughput on N MI355X GPUs + roofline of the metric kernel.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c1|c2|c5]
+
+One "step" = one pass of the whole hot path (minmax -> normalize -> pyramid reduce -> analysis ->
+contrast/noise-reduction + expand -> gradation) over one batch of synthetic raw images that is
+already resident in HBM. Default workload "c3" is BASELINE.json configs[3] seen from one GPU:
+8 independent 2048 x 2048 16-bit images, 6-level pyramid, per GPU and per step (weak scaling;
+at N = 8 that is the 64-image batch, at N = 1 it is 8 x configs[1]). Images are sharded
+one-shard-per-GPU with no data-path collective; RCCL is used once, inside the timed region, to
+all-gather the per-image summary statistics (musica_stats) of the final step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): value = megapixels/s of the whole
+job, plus
+  roofline     : the fused 5-tap smooth + 2x downsample kernel at level 0 (the kernel BASELINE.json's
+                 metric names), timed with HIP events on the library's stream inside the timed steps;
+                 achieved = 5 * S^2 * 4 B... i.e. (4 + 1) bytes per input pixel * pixels per launch / mean duration;
+  roofline_4096: the same kernel launched stand-alone on one 4096 x 4096 f32 image (BASELINE target);
+  kernels      : per-kernel-family mean duration, algorithmic GB/s and share of the step;
+  cpu_baseline : the CPU oracle (a port: the reference has no CPU path) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (image side, levels, images per GPU per step, bits, flags, description)
+    "c3": (2048, 6, 8, 16, 0, "8 x 2048x2048 u16 per GPU per step, 6-level pyramid (BASELINE configs[3] shard = 8 x configs[1])"),
+    "c1": (2048, 6, 1, 16, 0, "1 x 2048x2048 u16, 6-level pyramid (BASELINE configs[1])"),
+    "c2": (4096, 8, 1, 16, 1, "1 x 4096x4096 u16, 8-level pyramid + CLAHE gradation (BASELINE configs[2])"),
+    "c5": (8192, 10, 1, 12, 0, "1 x 8192x8192 12-bit, 10-level pyramid, noise reduction on (BASELINE configs[4])"),
+}
+
+
+def algorithmic_bytes(n, levels, batch):
+    """Algorithmic HBM bytes per launch of each kernel family, f32 = 4 B, u16 = 2 B."""
+    s = [n]
+    for _ in range(levels):
+        s.append((s[-1] + 1) // 2)
+    p = [v * v for v in s]
+    rest = range(1, levels)
+    return {
+        "minmax": 2 * p[0] * batch,
+        "normalize": 6 * p[0] * batch,
+        "reduce_l0": (4 * p[0] + 4 * p[1]) * batch,                      # read S^2 f32 once, write (S/2)^2 once
+        "reduce_rest": sum(4 * p[i] + 4 * p[i + 1] for i in rest) * batch / max(1, len(rest)),
+        "band_l0": (8 * p[0] + 4 * p[1]) * batch,                        # read fine + coarse, write band
+        "band_rest": sum(8 * p[i] + 4 * p[i + 1] for i in rest) * batch / max(1, len(rest)),
+        "sdev_hist": sum(8 * p[i] for i in range(4)) * batch / 4.0,      # read band, write sdev (hist in LDS)
+        "expand_l0": (12 * p[0] + 4 * p[1]) * batch,                     # read band + sdev + coarse, write recon
+        "expand_rest": (sum(12 * p[i] + 4 * p[i + 1] for i in range(1, 4)) +
+                        sum(8 * p[i] + 4 * p[i + 1] for i in range(4, levels))) * batch / max(1, len(rest)),
+        "grad_hist": 8 * p[0] * batch,                                   # read recon + normalized
+        "grad_apply": 8 * p[0] * batch,                                  # read recon, write graded
+        "curves": 4 * 2048 * 4 * batch,
+        "cnr": 8 * p[3] * batch,
+        "grad_curve": 4 * 1024 * batch,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed steps")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+    import numpy as np
+    import torch  # first: libmusica_hip.so then binds to the HIP runtime torch already loaded
+    import torch.distributed as dist
+
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd import processing as mp
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.phantom import phantom
+
+    if not torch.cuda.is_available() or mp.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the MUSICA path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n, levels, batch, bits, flags, desc = WORKLOADS[args.workload]
+    seeds = [100 + rank * batch + k for k in range(batch)]          # C4 uses default_rng(100 + k)
+    px = np.stack([phantom(n, s, bits=bits) for s in seeds])
+
+    proc = mp.MusicaProcessing(device=local_rank)
+    if not proc.init(n, levels=levels, batch=batch, flags=flags):
+        raise SystemExit("musica_create failed: " + mp.last_error())
+    proc.upload(px)                                                # inputs resident in HBM before the timed region
+
+    stats_words = 17                                               # sizeof(musica_stats) / 4
+    d_stats = torch.zeros((batch, stats_words), dtype=torch.int32, device="cuda")
+    gathered = torch.zeros((world * batch, stats_words), dtype=torch.int32, device="cuda")
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+
+    def step():
+        if not proc.execute_device():
+            raise SystemExit("musica_execute_device failed: " + mp.last_error())
+
+    for _ in range(args.warmup):
+        step()
+    proc.sync()
+
+    # HIP events on the library's stream around the metric kernel only (2 records per step);
+    # bracketing all ~33 launches costs ~18 % of the step, so the full table comes from a second pass
+    kernel_events = not args.no_kernel_events
+    proc.profile_reset()
+    proc.profile_enable(["reduce_l0"] if kernel_events else False)
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    proc.stats_device(d_stats.data_ptr(), image_id_base=rank * batch)
+    proc.sync()
+    if distributed:
+        dist.all_gather_into_tensor(gathered, d_stats)            # RCCL over xGMI: the only inter-GPU traffic
+    else:
+        gathered.copy_(d_stats)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+
+    elapsed = t1 - t0
+    if distributed:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    proc.profile_enable(False)
+    prof_timed = proc.profile()
+    # second, untimed pass over the same steps with every kernel family bracketed -> "kernels" table
+    proc.profile_reset()
+    proc.profile_enable(True)
+    for _ in range(args.steps):
+        step()
+    proc.sync()
+    proc.profile_enable(False)
+    prof = proc.profile()
+    if kernel_events and prof_timed["reduce_l0"][1]:
+        prof["reduce_l0"] = prof_timed["reduce_l0"]              # the live measurement of the timed region wins
+
+    result = None
+    if rank == 0:
+        mpix = world * batch * n * n * args.steps / 1e6
+        ms_per_step = elapsed / args.steps * 1e3
+        ab = algorithmic_bytes(n, levels, batch)
+        kernels = {}
+        total_kernel_us = 0.0
+        for name, (us, cnt) in prof.items():
+            if cnt:
+                total_kernel_us += us * cnt / args.steps
+        for name, (us, cnt) in prof.items():
+            if not cnt:
+                continue
+            gbs = ab.get(name, 0) / (us * 1e-6) / 1e9 if us > 0 else 0.0
+            kernels[name] = {"mean_us": round(us, 2), "launches_per_step": cnt // args.steps, "alg_GBps": round(gbs, 1),
+                             "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                             "share_of_step": round(us * cnt / args.steps / max(total_kernel_us, 1e-9), 4)}
+        roofline = None
+        if "reduce_l0" in kernels:
+            k = kernels["reduce_l0"]
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(args.workload, {}).get("reduce_l0_hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"kernel": "k_reduce_fast (5-tap smooth + 2x downsample, level 0, %d images of %dx%d per launch)" % (batch, n, n),
+                        "bound": "hbm", "achieved": k["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(k["alg_GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": ab["reduce_l0"], "mean_us": k["mean_us"]}
+        # the BASELINE target: the same kernel alone on one 4096 x 4096 f32 image, back-to-back launches
+        us4096 = proc.k_reduce_timed(4096, batch=1, iters=200)
+        b4096 = 5 * 4096 * 4096
+        roofline_4096 = {"kernel": "k_reduce_fast stand-alone, 4096x4096 f32, 200 back-to-back launches (input stays in Infinity Cache)",
+                         "bound": "hbm", "achieved": round(b4096 / (us4096 * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(b4096 / (us4096 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "mean_us": round(us4096, 2),
+                         "algorithmic_bytes_per_launch": b4096}
+        # CPU baseline: the oracle (a port — the reference has no CPU path), all host cores, bounded sample
+        cpu = None
+        if args.cpu_seconds > 0 and world == 1:
+            from oracle import binding as ob
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
+            cores = max(1, min(cores, 16))                         # a one-GPU box owns a 16-core share of the host
+            ob.set_threads(cores)
+            o = ob.Oracle(n, levels, ob.ORDER_FAST, flags & 1)
+            o.execute(px[0])                                       # warm-up (page faults, thread pool)
+            done, tc0 = 0, time.perf_counter()
+            while True:
+                o.execute(px[done % batch])
+                done += 1
+                if time.perf_counter() - tc0 >= args.cpu_seconds or done >= 64:
+                    break
+            tc = time.perf_counter() - tc0
+            cpu = {"value": round(done * n * n / 1e6 / tc, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+                   "sample": "%d x %dx%d images, %d-level pyramid, oracle MUSICA_ORDER_FAST with OpenMP on %d threads, %.1f s"
+                             % (done, n, n, levels, cores, tc)}
+        st = gathered.cpu().numpy()
+        result = {
+            "metric": "megapixels/sec full MUSICA pipeline", "value": round(mpix / elapsed, 1), "unit": "MP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "image_size": n, "levels": levels, "images_per_gpu_per_step": batch,
+                       "input": "seeded phantoms, %d-bit" % bits, "kernel_events_in_timed_region": kernel_events,
+                       "stats_gathered": int(st.shape[0])},
+            "roofline": roofline, "roofline_4096": roofline_4096, "cpu_baseline": cpu, "kernels": kernels,
+        }
+    proc.cleanup()
+    if distributed:
+        dist.destroy_process_group()
+    if result is not None:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -212,6 +212,10 @@ int musica_get_contrast_params(musica_ctx* ctx, uint32_t level, musica_contrast_
 int musica_get_nr_params(musica_ctx* ctx, uint32_t level /*0..2*/, musica_nr_params* dst);
 int musica_get_minmax(musica_ctx* ctx, uint32_t image_index, float* min_sqrt, float* max_sqrt);
 int musica_get_stats(musica_ctx* ctx, uint32_t image_index, musica_stats* dst);
+/* Writes the musica_stats of every image of the batch (batch * sizeof(musica_stats) bytes,
+ * image_id = image_id_base + index) into caller-owned DEVICE memory, asynchronously on the ctx
+ * stream: the buffer the multi-GPU batch driver hands to its RCCL all-gather. */
+int musica_stats_device(musica_ctx* ctx, void* d_dst, uint32_t image_id_base);
 /* CLAHE state (only with MUSICA_FLAG_CLAHE): 4*4*256 u32 histograms [tx][ty][bin], 4*4*256 curve points. */
 int musica_get_clahe_hist(musica_ctx* ctx, uint32_t image_index, uint32_t* dst);
 int musica_get_clahe_curves(musica_ctx* ctx, uint32_t image_index, musica_point* dst);
@@ -233,9 +237,10 @@ int musica_debug_set_image(musica_ctx* ctx, uint32_t image_index, musica_image_k
 int musica_debug_run_stage(musica_ctx* ctx, musica_stage stage);
 
 /* Per-kernel device timing with HIP events on the ctx stream.
- * musica_profile_enable(ctx, 1) makes every later execute bracket each kernel
- * family with events (eager launches); musica_profile_get returns the mean
- * duration in microseconds and the launch count since the last reset. */
+ * musica_profile_enable(ctx, mask): mask < 0 brackets every kernel family of every
+ * later execute with an event pair, mask > 0 only the families whose bit
+ * (1 << musica_kernel_id) is set, 0 switches it off. musica_profile_get returns
+ * the mean duration in microseconds and the launch count since the last reset. */
 typedef enum musica_kernel_id {
     MUSICA_KERNEL_MINMAX = 0,
     MUSICA_KERNEL_NORMALIZE = 1,
@@ -253,7 +258,7 @@ typedef enum musica_kernel_id {
     MUSICA_KERNEL_GRAD_APPLY = 13,
     MUSICA_KERNEL_COUNT = 14
 } musica_kernel_id;
-int musica_profile_enable(musica_ctx* ctx, int enabled);
+int musica_profile_enable(musica_ctx* ctx, int mask);
 int musica_profile_reset(musica_ctx* ctx);
 int musica_profile_get(musica_ctx* ctx, musica_kernel_id id, double* mean_us, uint64_t* launches);
 

@@ -147,24 +147,47 @@ struct SRow {
     float h0, h1;  // squares of columns c+8, c+9   (lane 63)
 };
 
-__device__ __forceinline__ void load_srow(SRow& r, const float* __restrict__ base, int pitch, int S, int row, int c, bool lane0,
-                                          bool lane63) {
+// Byte offsets of one lane inside a row; kOob where the access would leave the image (reads as 0: Q1).
+struct SCfg {
+    int c;
+    uint32_t off0, off1;  // 16-byte groups c .. c+3, c+4 .. c+7
+    uint32_t off_l;       // c-2, c-1 (lane 0)
+    uint32_t off_r;       // c+8, c+9 (lane 63)
+    int valid;            // number of in-image columns among the lane's 8 (pad columns of a pitched row must read as 0)
+    bool lane0, lane63;
+};
+
+__device__ __forceinline__ SCfg make_scfg(int strip, int lane, int S) {
+    SCfg g;
+    g.c = strip * kStripCols + lane * kLaneCols;
+    g.lane0 = lane == 0;
+    g.lane63 = lane == 63;
+    g.valid = min(max(S - g.c, 0), 8);
+    g.off0 = g.c < S ? (uint32_t)g.c * 4u : kOob;
+    g.off1 = g.c + 4 < S ? (uint32_t)(g.c + 4) * 4u : kOob;
+    g.off_l = (g.lane0 && g.c >= 2 && g.c < S) ? (uint32_t)(g.c - 2) * 4u : kOob;
+    g.off_r = (g.lane63 && g.c + 8 < S) ? (uint32_t)(g.c + 8) * 4u : kOob;
+    return g;
+}
+
+// row_off = kOob for rows outside the image. Columns >= S inside the last 16-byte group and the odd
+// right-halo column are masked to 0 by `valid` / `right_valid`.
+__device__ __forceinline__ void load_srow(SRow& r, const Buf& b, uint32_t row_off, const SCfg& g, int S) {
+    // kOob has only bit 31 set and every in-image offset is < 2^31, so an OR keeps "either one out of range" out of range
+    const float4 a = bload4(b, (g.off0 + row_off) | ((g.off0 | row_off) & kOob));
+    const float4 d = bload4(b, (g.off1 + row_off) | ((g.off1 | row_off) & kOob));
+    const float2 l = bload2(b, (g.off_l + row_off) | ((g.off_l | row_off) & kOob));
+    const float2 h = bload2(b, (g.off_r + row_off) | ((g.off_r | row_off) & kOob));
+    float v[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
 #pragma unroll
-    for (int j = 0; j < 8; j++) r.q[j] = 0.f;
-    r.l0 = r.l1 = r.h0 = r.h1 = 0.f;
-    if (row < 0 || row >= S) return;  // Q1: out-of-image rows are zeros
-    const float* p = base + (size_t)row * pitch;
-    const float4 a = load4_guard(p, c, S), b = load4_guard(p, c + 4, S);
-    r.q[0] = a.x * a.x; r.q[1] = a.y * a.y; r.q[2] = a.z * a.z; r.q[3] = a.w * a.w;
-    r.q[4] = b.x * b.x; r.q[5] = b.y * b.y; r.q[6] = b.z * b.z; r.q[7] = b.w * b.w;
-    if (lane0 && c >= 2) {
-        const float u = p[c - 2], v = p[c - 1];
-        r.l0 = u * u; r.l1 = v * v;
+    for (int j = 0; j < 8; j++) {
+        const float t = j < g.valid ? v[j] : 0.0f;
+        r.q[j] = t * t;
     }
-    if (lane63) {
-        if (c + 8 < S) { const float u = p[c + 8]; r.h0 = u * u; }
-        if (c + 9 < S) { const float u = p[c + 9]; r.h1 = u * u; }
-    }
+    r.l0 = l.x * l.x; r.l1 = l.y * l.y;
+    r.h0 = h.x * h.x;
+    const float h1 = (g.c + 9 < S) ? h.y : 0.0f;
+    r.h1 = h1 * h1;
 }
 
 __device__ __forceinline__ float sum5(float a, float b, float c, float d, float e) {
@@ -176,8 +199,66 @@ __device__ __forceinline__ float sum5(float a, float b, float c, float d, float 
     return acc;
 }
 
-// rows_per_wave must be a multiple of 16 (histogram runs start at y % 16 == 0).
+// One output row of sdev from its five rows of squares + the histogram scan of that row.
+__device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const SRow& r2, const SRow& r3, const SRow& r4, const SCfg& g, int S,
+                                         int y, int cov, float* __restrict__ drow, uint32_t* lh, uint32_t& alive) {
+    float q[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) q[j] = sum5(r0.q[j], r1.q[j], r2.q[j], r3.q[j], r4.q[j]);
+    const float ql0 = sum5(r0.l0, r1.l0, r2.l0, r3.l0, r4.l0), ql1 = sum5(r0.l1, r1.l1, r2.l1, r3.l1, r4.l1);
+    const float qh0 = sum5(r0.h0, r1.h0, r2.h0, r3.h0, r4.h0), qh1 = sum5(r0.h1, r1.h1, r2.h1, r3.h1, r4.h1);
+    float a6 = from_left_lane(q[6]), a7 = from_left_lane(q[7]);
+    float b0 = from_right_lane(q[0]), b1 = from_right_lane(q[1]);
+    if (g.lane0) { a6 = ql0; a7 = ql1; }    // zeros at the image's left edge (loads out of range)
+    if (g.lane63) { b0 = qh0; b1 = qh1; }   // zeros beyond the right edge
+    // lanes right of the image hold q == 0, so the last in-image lane reads zeros from its neighbour
+    float s[8];
+    s[0] = sum5(a6, a7, q[0], q[1], q[2]);
+    s[1] = sum5(a7, q[0], q[1], q[2], q[3]);
+    s[2] = sum5(q[0], q[1], q[2], q[3], q[4]);
+    s[3] = sum5(q[1], q[2], q[3], q[4], q[5]);
+    s[4] = sum5(q[2], q[3], q[4], q[5], q[6]);
+    s[5] = sum5(q[3], q[4], q[5], q[6], q[7]);
+    s[6] = sum5(q[4], q[5], q[6], q[7], b0);
+    s[7] = sum5(q[5], q[6], q[7], b0, b1);
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = sqrtf(s[j] / 25.0f);  // img_sdev.comp:30
+    if (g.valid == 8) {
+        *reinterpret_cast<float4*>(drow + g.c) = make_float4(s[0], s[1], s[2], s[3]);
+        *reinterpret_cast<float4*>(drow + g.c + 4) = make_float4(s[4], s[5], s[6], s[7]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j < g.valid) drow[g.c + j] = s[j];
+    }
+    // noise_hist.comp:20-47
+    if ((y & (kHistArea - 1)) == 0) alive = 0xFFu;
+    if (y < cov) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (!(alive & (1u << j))) continue;
+            const int x = g.c + j;
+            const float cur = (j < g.valid && x < cov) ? s[j] : 0.0f;
+            bool brk = (cur == 0.0f);                                   // :29
+            int bin = 0;
+            if (!brk) {
+                const float adj = cur / kMaxNoiseValue;                   // :31
+                if (adj > 1.0f) brk = true;                               // :33
+                else {
+                    bin = (int)(adj * (float)MUSICA_NOISE_BINS + 0.5f);   // :35
+                    if (bin == 0) brk = true;                             // :39
+                }
+            }
+            if (brk) alive &= ~(1u << j);
+            else if (bin > 0 && bin < MUSICA_NOISE_BINS) atomicAdd(&lh[bin], 1u);  // :45 (bin 2048 is dropped, Q1)
+        }
+    }
+}
+
+// rows_per_wave must be a multiple of 16 (histogram runs start at y % 16 == 0) and of T.
 // cov = (imageSize / 512) * 512: the part of the grid the reference's dispatch covers (src/vk_processing.cpp:2293-2295).
+// T rows per loop trip: the T new rows are loaded back to back before any arithmetic.
+template <int T>
 __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
                                                              size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov,
                                                              int rows_per_wave) {
@@ -185,79 +266,32 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist(const float* __rest
     for (int i = threadIdx.x; i < MUSICA_NOISE_BINS; i += blockDim.x) lh[i] = 0u;
     __syncthreads();
     const int img = blockIdx.z;
-    band += (size_t)img * plane;
+    const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
     sdev += (size_t)img * plane;
     const int lane = threadIdx.x & 63;
     const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
     const int y0 = seg * rows_per_wave;
-    const int c = blockIdx.x * kStripCols + lane * kLaneCols;
-    const bool lane0 = lane == 0, lane63 = lane == 63;
+    const SCfg g = make_scfg(blockIdx.x, lane, S);
+    const uint32_t rb = (uint32_t)pitch * 4u;
+    auto roff = [&](int row) -> uint32_t { return (row >= 0 && row < S) ? (uint32_t)row * rb : kOob; };
     if (y0 < S) {
         const int y1 = min(y0 + rows_per_wave, S);
-        SRow r0, r1, r2, r3, r4, nx;
-        load_srow(r0, band, pitch, S, y0 - 2, c, lane0, lane63);
-        load_srow(r1, band, pitch, S, y0 - 1, c, lane0, lane63);
-        load_srow(r2, band, pitch, S, y0, c, lane0, lane63);
-        load_srow(r3, band, pitch, S, y0 + 1, c, lane0, lane63);
-        load_srow(r4, band, pitch, S, y0 + 2, c, lane0, lane63);
+        SRow w[T + 4];  // rows y-2 .. y+T+1
+        load_srow(w[0], bb, roff(y0 - 2), g, S);
+        load_srow(w[1], bb, roff(y0 - 1), g, S);
+        load_srow(w[2], bb, roff(y0), g, S);
+        load_srow(w[3], bb, roff(y0 + 1), g, S);
         uint32_t alive = 0;
-        for (int y = y0; y < y1; y++) {
-            load_srow(nx, band, pitch, S, y + 3, c, lane0, lane63);
-            float q[8];
+        for (int y = y0; y < y1; y += T) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) q[j] = sum5(r0.q[j], r1.q[j], r2.q[j], r3.q[j], r4.q[j]);
-            const float ql0 = sum5(r0.l0, r1.l0, r2.l0, r3.l0, r4.l0), ql1 = sum5(r0.l1, r1.l1, r2.l1, r3.l1, r4.l1);
-            const float qh0 = sum5(r0.h0, r1.h0, r2.h0, r3.h0, r4.h0), qh1 = sum5(r0.h1, r1.h1, r2.h1, r3.h1, r4.h1);
-            float a6 = from_left_lane(q[6]), a7 = from_left_lane(q[7]);
-            float b0 = from_right_lane(q[0]), b1 = from_right_lane(q[1]);
-            if (lane0) { a6 = ql0; a7 = ql1; }    // zeros at the image's left edge (loads skipped)
-            if (lane63) { b0 = qh0; b1 = qh1; }   // zeros beyond the right edge
-            // lanes right of the image hold q == 0, so the last in-image lane reads zeros from its neighbour
-            float s[8];
-            s[0] = sum5(a6, a7, q[0], q[1], q[2]);
-            s[1] = sum5(a7, q[0], q[1], q[2], q[3]);
-            s[2] = sum5(q[0], q[1], q[2], q[3], q[4]);
-            s[3] = sum5(q[1], q[2], q[3], q[4], q[5]);
-            s[4] = sum5(q[2], q[3], q[4], q[5], q[6]);
-            s[5] = sum5(q[3], q[4], q[5], q[6], q[7]);
-            s[6] = sum5(q[4], q[5], q[6], q[7], b0);
-            s[7] = sum5(q[5], q[6], q[7], b0, b1);
+            for (int t = 0; t < T; t++) load_srow(w[t + 4], bb, roff(y + t + 2), g, S);
 #pragma unroll
-            for (int j = 0; j < 8; j++) s[j] = sqrtf(s[j] / 25.0f);  // img_sdev.comp:30
-            if (c < S) {
-                float* d = sdev + (size_t)y * pitch + c;
-                if (c + 8 <= S) {
-                    *reinterpret_cast<float4*>(d) = make_float4(s[0], s[1], s[2], s[3]);
-                    *reinterpret_cast<float4*>(d + 4) = make_float4(s[4], s[5], s[6], s[7]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        if (c + j < S) d[j] = s[j];
-                }
+            for (int t = 0; t < T; t++) {
+                if (y + t < y1)  // wave-uniform
+                    sdev_row(w[t], w[t + 1], w[t + 2], w[t + 3], w[t + 4], g, S, y + t, cov, sdev + (size_t)(y + t) * pitch, lh, alive);
             }
-            // noise_hist.comp:20-47
-            if ((y & (kHistArea - 1)) == 0) alive = 0xFFu;
-            if (y < cov) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    if (!(alive & (1u << j))) continue;
-                    const int x = c + j;
-                    const float cur = (x < S && x < cov) ? s[j] : 0.0f;
-                    bool brk = (cur == 0.0f);                                   // :29
-                    int bin = 0;
-                    if (!brk) {
-                        const float adj = cur / kMaxNoiseValue;                   // :31
-                        if (adj > 1.0f) brk = true;                               // :33
-                        else {
-                            bin = (int)(adj * (float)MUSICA_NOISE_BINS + 0.5f);   // :35
-                            if (bin == 0) brk = true;                             // :39
-                        }
-                    }
-                    if (brk) alive &= ~(1u << j);
-                    else if (bin > 0 && bin < MUSICA_NOISE_BINS) atomicAdd(&lh[bin], 1u);  // :45 (bin 2048 is dropped, Q1)
-                }
-            }
-            r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = nx;
+            for (int i = 0; i < 4; i++) w[i] = w[T + i];
         }
     }
     __syncthreads();
@@ -373,11 +407,17 @@ __global__ void k_cnr(const float* __restrict__ sdev, float* __restrict__ cnr, i
     cnr[o] = v / kMaxCnrValue;                                                                  // :43
 }
 
-// Deterministic per-image sum of the cnr image in double (for musica_stats.mean_cnr):
-// one block per image, fixed partition, fixed tree.
-__global__ __launch_bounds__(256) void k_sum_image(const float* __restrict__ img, int S, int pitch, size_t plane, double* __restrict__ out) {
+// Per-image summary (musica_stats) written on the device so the batch driver can all-gather it with
+// RCCL without a host round trip. mean_cnr = mean(cnr image) * 256 — what test/mean_cnr/script.py:13-24
+// prints for a cnr.bmp dump — summed in double with a fixed partition and a fixed tree (deterministic).
+__global__ __launch_bounds__(256) void k_stats(const float* __restrict__ cnr, int S, int pitch, size_t plane,
+                                               const uint32_t* __restrict__ minmax, int min_chain_exact,
+                                               const musica_hist_max_point* __restrict__ noise_max, int levels,
+                                               const musica_hist_max_point* __restrict__ grad_max, const DevCurve* __restrict__ gcurve,
+                                               musica_stats* __restrict__ out, uint32_t image_id_base) {
     __shared__ double part[256];
-    const float* p = img + (size_t)blockIdx.x * plane;
+    const int img = blockIdx.x;
+    const float* p = cnr + (size_t)img * plane;
     double acc = 0.0;
     for (int y = 0; y < S; y++)
         for (int x = threadIdx.x; x < S; x += blockDim.x) acc += (double)p[(size_t)y * pitch + x];
@@ -387,7 +427,22 @@ __global__ __launch_bounds__(256) void k_sum_image(const float* __restrict__ img
         if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+    if (threadIdx.x != 0) return;
+    musica_stats st;
+    st.image_id = image_id_base + (uint32_t)img;
+    chain_scalars(minmax, img, min_chain_exact, st.min_sqrt, st.max_sqrt);
+    for (int l = 0; l < 4; l++) {
+        const musica_hist_max_point mp = noise_max[(size_t)img * levels + l];
+        st.noise_max_bin[l] = mp.maxBin;
+        st.noise_max_value[l] = mp.maxValue;
+    }
+    st.grad_max_bin = grad_max[img].maxBin;
+    st.grad_max_value = grad_max[img].maxValue;
+    st.mean_cnr = (float)(part[0] / ((double)S * (double)S) * 256.0);
+    st.t0 = gcurve[img].t0;
+    st.ta = gcurve[img].ta;
+    st.t1 = gcurve[img].t1;
+    out[img] = st;
 }
 
 // ======================================================================================
@@ -402,7 +457,7 @@ void launch_clear(hipStream_t st, uint32_t* minmax, uint32_t* noise_hist, uint32
 
 void launch_minmax(hipStream_t st, const uint16_t* px, int N, uint32_t* minmax, int batch) {
     const size_t count = (size_t)N * N;
-    int blocks = (int)std::min<size_t>((count / 8 + 255) / 256, (size_t)1024);
+    int blocks = (int)std::min<size_t>((count / 8 + 255) / 256, (size_t)std::max(32, 2048 / std::max(batch, 1)));
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_minmax_u16, dim3(blocks, 1, batch), dim3(256), 0, st, px, count, minmax);
 }
@@ -423,7 +478,7 @@ void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const Leve
                       int batch, int rows_per_wave) {
     const int strips = (l.S + kStripCols - 1) / kStripCols;
     const int segs = (l.S + rows_per_wave - 1) / rows_per_wave;
-    hipLaunchKernelGGL(k_sdev_hist, dim3(strips, (segs + kWavesPerBlock - 1) / kWavesPerBlock, batch), dim3(kBlockThreads), 0, st, band,
+    hipLaunchKernelGGL(k_sdev_hist<4>, dim3(strips, (segs + kWavesPerBlock - 1) / kWavesPerBlock, batch), dim3(kBlockThreads), 0, st, band,
                        sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
 }
 
@@ -443,8 +498,11 @@ void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& 
                        maxpts, levels);
 }
 
-void launch_sum_image(hipStream_t st, const float* img, const LevelDesc& l, double* out, int batch) {
-    hipLaunchKernelGGL(k_sum_image, dim3(batch), dim3(256), 0, st, img, l.S, l.pitch, l.plane, out);
+void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact,
+                  const musica_hist_max_point* noise_max, int levels, const musica_hist_max_point* grad_max, const DevCurve* gcurve,
+                  musica_stats* out, uint32_t image_id_base, int batch) {
+    hipLaunchKernelGGL(k_stats, dim3(batch), dim3(256), 0, st, cnr, l3.S, l3.pitch, l3.plane, minmax, min_chain_exact, noise_max, levels,
+                       grad_max, gcurve, out, image_id_base);
 }
 
 }  // namespace musica

@@ -14,6 +14,58 @@ __device__ __forceinline__ float from_right_lane(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
 }
 
+// ---- branch-free memory access through buffer descriptors ----
+// A raw buffer load whose byte offset lies outside the descriptor returns 0 and touches no memory;
+// a store there is dropped. Lanes that must not access memory therefore just carry kOob as their
+// offset: no `if` around a load, so hipcc never parks an s_waitcnt inside a divergent block and a
+// wavefront can keep every load of a loop trip in flight. It is also exactly the reference's
+// "out-of-bounds imageLoad returns 0 / imageStore is dropped" rule.
+// Descriptors are built from wave-uniform values only (one image plane, < 2 GiB).
+// (ROCm 7.2's __builtin_amdgcn_raw_buffer_load_b64/_b128 lower to a single-dword load that is then
+// splatted, so the LLVM intrinsics are bound directly by their names.)
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ v4f llvm_buffer_load_v4f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ v2f llvm_buffer_load_v2f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ float llvm_buffer_load_f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ void llvm_buffer_store_v4f32(v4f data, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+constexpr uint32_t kOob = 0x80000000u;
+
+struct Buf {
+    v4i r;
+};
+// {base address, num_records (bytes), 0x00020000 = 32-bit untyped data format on gfx9}
+__device__ __forceinline__ Buf make_buf(const void* p, size_t bytes) {
+    union {
+        v4i v;
+        struct { const void* p; uint32_t range; uint32_t cfg; } s;
+    } u;
+    u.s.p = p;
+    u.s.range = (uint32_t)(bytes < 0x7FFFFFF0u ? bytes : 0x7FFFFFF0u);
+    u.s.cfg = 0x00020000u;
+    Buf b;
+    b.r.x = __builtin_amdgcn_readfirstlane(u.v.x);
+    b.r.y = __builtin_amdgcn_readfirstlane(u.v.y);
+    b.r.z = __builtin_amdgcn_readfirstlane(u.v.z);
+    b.r.w = __builtin_amdgcn_readfirstlane(u.v.w);
+    return b;
+}
+__device__ __forceinline__ float4 bload4(const Buf& b, uint32_t off) {
+    const v4f v = llvm_buffer_load_v4f32(b.r, (int)off, 0, 0);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 bload2(const Buf& b, uint32_t off) {
+    const v2f v = llvm_buffer_load_v2f32(b.r, (int)off, 0, 0);
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ float bload1(const Buf& b, uint32_t off) { return llvm_buffer_load_f32(b.r, (int)off, 0, 0); }
+__device__ __forceinline__ void bstore4(const Buf& b, uint32_t off, float4 v) {
+    v4f u;
+    u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
+    llvm_buffer_store_v4f32(u, b.r, (int)off, 0, 0);
+}
+
 // ---- arithmetic in the oracle's MUSICA_ORDER_FAST order ----
 // ((((w0*a + w1*b) + w2*c) + w3*d) + w4*e), products and sums rounded separately.
 __device__ __forceinline__ float chain5(float a, float b, float c, float d, float e) {

@@ -39,12 +39,15 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
     for (int i = threadIdx.x; i < MUSICA_GRAD_BINS; i += blockDim.x) lh[i] = 0u;
     __syncthreads();
     const int img = blockIdx.z;
-    const float* im = a.img + (size_t)img * a.plane;
-    const float* nm = a.normalized + (size_t)img * a.plane;
+    const Buf ib = make_buf(a.img + (size_t)img * a.plane, a.plane * 4);
+    const Buf nb = make_buf(a.normalized + (size_t)img * a.plane, a.plane * 4);
     const float* cn = a.cnr + (size_t)img * a.cnrPlane;
     const int lane = threadIdx.x & 63;
     const int N = a.N;
     const int c = blockIdx.x * 256 + lane * 4;
+    const int valid = min(max(N - c, 0), 4);                  // in-image columns among the lane's 4
+    const uint32_t coff = c < N ? (uint32_t)c * 4u : kOob;
+    const uint32_t rb = (uint32_t)a.pitch * 4u;
     const int mbase = (lane & 3) * 4;
     const int g0 = (blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)) * a.groups_per_wave;
     for (int gi = 0; gi < a.groups_per_wave; gi++) {
@@ -54,7 +57,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
 #pragma unroll
         for (int n = 0; n < kHistArea; n++) {
             const int y = yb + n;
-            v[n] = (y < N) ? load4_guard(im + (size_t)y * a.pitch, c, N) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[n] = bload4(ib, (y < N ? (uint32_t)y * rb : kOob) + coff);   // out of image reads 0 (Q1); kOob + kOob wraps to 0 only
+            if (valid < 4) {                                                // when both are out, and then c >= N masks it below
+                if (valid < 1) v[n].x = 0.f;
+                if (valid < 2) v[n].y = 0.f;
+                if (valid < 3) v[n].z = 0.f;
+                v[n].w = 0.f;
+            }
         }
         // first zero of each owned column, as a scan position m*16 + n (256 = none)
         int q = 256;
@@ -67,29 +76,36 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
         }
         q = min(q, __shfl_xor(q, 1));
         q = min(q, __shfl_xor(q, 2));
-        if (q == 0) continue;  // not wave-uniform, but nothing below crosses lanes
+        // two halves of 8 rows: the normalized rows of a half are loaded back to back, then binned
 #pragma unroll
-        for (int n = 0; n < kHistArea; n++) {
-            const int y = yb + n;
-            const float vv[4] = {v[n].x, v[n].y, v[n].z, v[n].w};
-            float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
-            bool have_pn = false;
+        for (int half = 0; half < 2; half++) {
+            float4 pn[8];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if ((mbase + j) * 16 + n >= q) continue;
-                const float cur = vv[j];
-                if (cur != cur) continue;                                         // NaN never indexes (oracle Q6)
-                const float scaled = cur * (float)MUSICA_GRAD_BINS;                // gradation_histogram.comp:26
-                if (!(scaled > -2147483648.0f && scaled < 2147483648.0f)) continue;
-                const int bin = (int)scaled;
-                if (bin < 0 || bin >= MUSICA_GRAD_BINS) continue;                  // Q1
-                const int x = c + j;
-                const float cc = cnr_at(cn, a.cnrS, a.cnrPitch, a.cnrScale, x, y);
-                if (!(cc >= 1.0f)) continue;                                       // relevant == 0 -> adds 0
-                if (!have_pn) { pn = load4_guard(nm + (size_t)y * a.pitch, c, N); have_pn = true; }
-                const float pix = j == 0 ? pn.x : j == 1 ? pn.y : j == 2 ? pn.z : pn.w;
-                const uint32_t w = f2u(relevant_of(pix, cc, (uint32_t)x, (uint32_t)y, (uint32_t)N) * 100.0f);  // :28-30
-                if (w) atomicAdd(&lh[bin], w);
+            for (int n = 0; n < 8; n++) {
+                const int y = yb + half * 8 + n;
+                pn[n] = bload4(nb, (y < N ? (uint32_t)y * rb : kOob) + coff);
+            }
+#pragma unroll
+            for (int n8 = 0; n8 < 8; n8++) {
+                const int n = half * 8 + n8;
+                const int y = yb + n;
+                const float vv[4] = {v[n].x, v[n].y, v[n].z, v[n].w};
+                const float pp[4] = {pn[n8].x, pn[n8].y, pn[n8].z, pn[n8].w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if ((mbase + j) * 16 + n >= q) continue;
+                    const float cur = vv[j];
+                    if (cur != cur) continue;                                         // NaN never indexes (oracle Q6)
+                    const float scaled = cur * (float)MUSICA_GRAD_BINS;                // gradation_histogram.comp:26
+                    if (!(scaled > -2147483648.0f && scaled < 2147483648.0f)) continue;
+                    const int bin = (int)scaled;
+                    if (bin < 0 || bin >= MUSICA_GRAD_BINS) continue;                  // Q1
+                    const int x = c + j;
+                    const float cc = cnr_at(cn, a.cnrS, a.cnrPitch, a.cnrScale, x, y);
+                    if (!(cc >= 1.0f)) continue;                                       // relevant == 0 -> adds 0
+                    const uint32_t w = f2u(relevant_of(pp[j], cc, (uint32_t)x, (uint32_t)y, (uint32_t)N) * 100.0f);  // :28-30
+                    if (w) atomicAdd(&lh[bin], w);
+                }
             }
         }
     }

@@ -7,11 +7,14 @@
 //
 // Streaming ("fast") form, used when the level side S is a multiple of 8: one 64-lane wavefront
 // owns a strip of 512 fine columns (8 per lane, two 16-byte loads per row) and marches down a
-// segment of rows keeping the 5-row window in registers; the vertical 5-tap pass runs straight
+// segment of rows keeping the row window in registers; the vertical 5-tap pass runs straight
 // from the loaded registers, the horizontal pass takes its 2+1 neighbour columns from the
-// adjacent lanes with DPP wave shifts (no LDS, no barrier) and from two predicated halo loads at
-// the strip edges. Every HBM byte is touched by exactly one 16-byte access of one lane, plus the
-// 3-row / 3-column halos that stay in the XCD's L2. Reflect-101 borders are register selects.
+// adjacent lanes with DPP wave shifts (no LDS, no barrier) and from two halo loads at the strip
+// edges. All memory access goes through buffer descriptors with per-lane byte offsets, so a lane
+// that has nothing to load carries an out-of-range offset instead of sitting behind an `if`:
+// the loop bodies are branch-free and every load of a trip is in flight before the first use.
+// Every HBM byte is touched by exactly one 16-byte access of one lane, plus the 3-row / 3-column
+// halos that stay in the XCD's L2. Reflect-101 borders are register selects.
 //
 // Generic form (any S, including the 1..7-pixel tail of the reference's 12-level pyramid):
 // one thread per output texel with the shaders' mirror()/out-of-bounds rules applied per tap.
@@ -21,6 +24,41 @@
 #include "launchers.h"
 
 namespace musica {
+
+// Per-lane geometry of a 512-column strip, as byte offsets inside one row.
+struct LaneCfg {
+    int c;               // first fine column of this lane
+    bool active;         // c < S
+    bool left_mirror;    // lane 0 of the first strip: columns -2, -1 mirror onto 2, 1
+    bool last_active;    // the lane holding column S-1: column S mirrors onto S-2
+    bool lane0, lane63;
+    uint32_t off;        // fine columns c .. c+7            (kOob when the lane is right of the image)
+    uint32_t off_l;      // fine columns c-2, c-1            (lane 0 of a strip that is not the first, else kOob)
+    uint32_t off_r;      // fine column  c+8                 (lane 63 with more image to its right, else kOob)
+    uint32_t coff;       // coarse columns c/2 .. c/2+3
+    uint32_t coff_l;     // coarse column  c/2-1
+    uint32_t coff_r;     // coarse column  c/2+4
+};
+
+__device__ __forceinline__ LaneCfg make_cfg(int strip, int lane, int S) {
+    LaneCfg g;
+    const int c0 = strip * kStripCols;
+    g.c = c0 + lane * kLaneCols;
+    g.active = g.c < S;
+    g.lane0 = lane == 0;
+    g.lane63 = lane == 63;
+    const bool left_load = g.lane0 && c0 > 0;
+    const bool right_load = g.lane63 && (g.c + kLaneCols < S);
+    g.left_mirror = g.lane0 && c0 == 0;
+    g.last_active = g.active && (g.c + kLaneCols >= S);
+    g.off = g.active ? (uint32_t)g.c * 4u : kOob;
+    g.off_l = left_load ? (uint32_t)(g.c - 2) * 4u : kOob;
+    g.off_r = right_load ? (uint32_t)(g.c + kLaneCols) * 4u : kOob;
+    g.coff = g.active ? (uint32_t)(g.c >> 1) * 4u : kOob;
+    g.coff_l = left_load ? (uint32_t)((g.c >> 1) - 1) * 4u : kOob;
+    g.coff_r = right_load ? (uint32_t)((g.c >> 1) + 4) * 4u : kOob;
+    return g;
+}
 
 // ======================================================================================
 // K5 + K6: out(xo, yo) = sum_m w[m] * ( sum_n w[n] * in(mirror(2xo+m-2), mirror(2yo+n-2)) )
@@ -32,52 +70,54 @@ struct RowR {
     float hr;        // column c0+512 of the strip (lane 63 only)
 };
 
-struct LaneCfg {
-    int c;            // first fine column of this lane
-    bool active;      // c < S
-    bool left_load;   // lane 0 of a strip that is not the first: halo comes from memory
-    bool left_mirror; // lane 0 of the first strip: columns -2, -1 mirror onto 2, 1
-    bool last_active; // the lane holding column S-1: column S mirrors onto S-2
-    bool right_load;  // lane 63 with more image to its right
-    bool lane0, lane63;
-};
-
-__device__ __forceinline__ LaneCfg make_cfg(int strip, int lane, int S) {
-    LaneCfg g;
-    const int c0 = strip * kStripCols;
-    g.c = c0 + lane * kLaneCols;
-    g.active = g.c < S;
-    g.lane0 = lane == 0;
-    g.lane63 = lane == 63;
-    g.left_load = g.lane0 && c0 > 0;
-    g.left_mirror = g.lane0 && c0 == 0;
-    g.last_active = g.active && (g.c + kLaneCols >= S);
-    g.right_load = g.lane63 && (g.c + kLaneCols < S);
-    return g;
+__device__ __forceinline__ void load8(float d[8], const Buf& b, uint32_t off) {
+    const float4 a = bload4(b, off), c = bload4(b, off + 16u);
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = c.x; d[5] = c.y; d[6] = c.z; d[7] = c.w;
+}
+__device__ __forceinline__ void store8(const Buf& b, uint32_t off, const float d[8]) {
+    bstore4(b, off, make_float4(d[0], d[1], d[2], d[3]));
+    bstore4(b, off + 16u, make_float4(d[4], d[5], d[6], d[7]));
 }
 
-__device__ __forceinline__ void load_row(RowR& r, const float* __restrict__ base, int pitch, int row, const LaneCfg& g) {
-    const float* p = base + (size_t)row * pitch;
-    if (g.active) {
-        float4 a = *reinterpret_cast<const float4*>(p + g.c);
-        float4 b = *reinterpret_cast<const float4*>(p + g.c + 4);
-        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-        r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-    }
-    if (g.left_load) {
-        float2 h = *reinterpret_cast<const float2*>(p + g.c - 2);
-        r.hl0 = h.x; r.hl1 = h.y;
-    }
-    if (g.right_load) r.hr = p[g.c + kLaneCols];
+__device__ __forceinline__ void load_row(RowR& r, const Buf& b, uint32_t row_off, const LaneCfg& g) {
+    load8(r.v, b, g.off + row_off);
+    const float2 h = bload2(b, g.off_l + row_off);
+    r.hl0 = h.x; r.hl1 = h.y;
+    r.hr = bload1(b, g.off_r + row_off);
 }
 
-__device__ __forceinline__ void zero_row(RowR& r) {
+// One output row from its five input rows (vertical pass in registers, horizontal pass with the
+// neighbour columns taken from the adjacent lanes).
+__device__ __forceinline__ void reduce_row(const RowR& r0, const RowR& r1, const RowR& r2, const RowR& r3, const RowR& r4,
+                                           const LaneCfg& g, const Buf& ob, uint32_t out_off) {
+    float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) r.v[j] = 0.f;
-    r.hl0 = r.hl1 = r.hr = 0.f;
+    for (int j = 0; j < 8; j++) v[j] = chain5(r0.v[j], r1.v[j], r2.v[j], r3.v[j], r4.v[j]);
+    const float vh0 = chain5(r0.hl0, r1.hl0, r2.hl0, r3.hl0, r4.hl0);
+    const float vh1 = chain5(r0.hl1, r1.hl1, r2.hl1, r3.hl1, r4.hl1);
+    const float vhr = chain5(r0.hr, r1.hr, r2.hr, r3.hr, r4.hr);
+    float vl6 = from_left_lane(v[6]);
+    float vl7 = from_left_lane(v[7]);
+    float vr0 = from_right_lane(v[0]);
+    if (g.lane0) {
+        vl6 = g.left_mirror ? v[2] : vh0;  // column -2 -> 2, -1 -> 1 (img_smooth.comp:13)
+        vl7 = g.left_mirror ? v[1] : vh1;
+    }
+    if (g.last_active) vr0 = v[6];         // column S -> S-2 (img_smooth.comp:12)
+    else if (g.lane63) vr0 = vhr;
+    float4 o;
+    o.x = chain5(vl6, vl7, v[0], v[1], v[2]);
+    o.y = chain5(v[0], v[1], v[2], v[3], v[4]);
+    o.z = chain5(v[2], v[3], v[4], v[5], v[6]);
+    o.w = chain5(v[4], v[5], v[6], v[7], vr0);
+    bstore4(ob, g.coff + out_off, o);      // output columns c/2 .. c/2+3; dropped for lanes right of the image
 }
 
 // grid: x = strips, y = ceil(segments / 4), z = batch. One wavefront = one (strip, segment).
+// T output rows per loop trip: the 2T new input rows (4T 16-byte loads per lane) are issued
+// back to back before any arithmetic, so a wavefront keeps 4T KiB in flight and the other
+// resident wavefronts of the SIMD cover its wait (no barrier, no LDS).
+template <int T>
 __global__ __launch_bounds__(kBlockThreads) void k_reduce_fast(const float* __restrict__ in, float* __restrict__ out,
                                                                int S, int pitch, size_t in_plane, int So, int opitch,
                                                                size_t out_plane, int rows_per_wave) {
@@ -86,48 +126,113 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_fast(const float* __re
     const int yo0 = seg * rows_per_wave;
     if (yo0 >= So) return;  // wave-uniform
     const int yo1 = min(yo0 + rows_per_wave, So);
-    in += (size_t)blockIdx.z * in_plane;
-    out += (size_t)blockIdx.z * out_plane;
+    const Buf ib = make_buf(in + (size_t)blockIdx.z * in_plane, in_plane * 4);
+    const Buf ob = make_buf(out + (size_t)blockIdx.z * out_plane, out_plane * 4);
     const LaneCfg g = make_cfg(blockIdx.x, lane, S);
     const int hi = S - 1;
+    const uint32_t rb = (uint32_t)pitch * 4u, orb = (uint32_t)opitch * 4u;
 
-    RowR r0, r1, r2, r3, r4, n3, n4;
-    zero_row(r0); zero_row(r1); zero_row(r2); zero_row(r3); zero_row(r4); zero_row(n3); zero_row(n4);
-    load_row(r0, in, pitch, mirror_idx(2 * yo0 - 2, hi), g);
-    load_row(r1, in, pitch, mirror_idx(2 * yo0 - 1, hi), g);
-    load_row(r2, in, pitch, 2 * yo0, g);
-    load_row(r3, in, pitch, mirror_idx(2 * yo0 + 1, hi), g);
-    load_row(r4, in, pitch, mirror_idx(2 * yo0 + 2, hi), g);
-
-    for (int yo = yo0; yo < yo1; yo++) {
-        if (yo + 1 < yo1) {  // prefetch the two new rows of the next output row
-            load_row(n3, in, pitch, mirror_idx(2 * yo + 3, hi), g);
-            load_row(n4, in, pitch, mirror_idx(2 * yo + 4, hi), g);
-        }
-        float v[8];
+    RowR w[2 * T + 3];  // input rows 2yo-2 .. 2yo+2T
+    load_row(w[0], ib, (uint32_t)mirror_idx(2 * yo0 - 2, hi) * rb, g);
+    load_row(w[1], ib, (uint32_t)mirror_idx(2 * yo0 - 1, hi) * rb, g);
+    load_row(w[2], ib, (uint32_t)(2 * yo0) * rb, g);
+    for (int yo = yo0; yo < yo1; yo += T) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = chain5(r0.v[j], r1.v[j], r2.v[j], r3.v[j], r4.v[j]);
-        const float vh0 = chain5(r0.hl0, r1.hl0, r2.hl0, r3.hl0, r4.hl0);
-        const float vh1 = chain5(r0.hl1, r1.hl1, r2.hl1, r3.hl1, r4.hl1);
-        const float vhr = chain5(r0.hr, r1.hr, r2.hr, r3.hr, r4.hr);
-        float vl6 = from_left_lane(v[6]);
-        float vl7 = from_left_lane(v[7]);
-        float vr0 = from_right_lane(v[0]);
-        if (g.lane0) {
-            vl6 = g.left_mirror ? v[2] : vh0;  // column -2 -> 2, -1 -> 1 (img_smooth.comp:13)
-            vl7 = g.left_mirror ? v[1] : vh1;
+        for (int t = 0; t < T; t++) {
+            // rows past the segment are clamped onto valid rows: loaded, never consumed
+            const int ya = min(yo + t, yo1 - 1);
+            load_row(w[2 * t + 3], ib, (uint32_t)mirror_idx(2 * ya + 1, hi) * rb, g);
+            load_row(w[2 * t + 4], ib, (uint32_t)mirror_idx(2 * ya + 2, hi) * rb, g);
         }
-        if (g.last_active) vr0 = v[6];         // column S -> S-2 (img_smooth.comp:12)
-        else if (g.lane63) vr0 = vhr;
-        if (g.active) {
-            float4 o;
-            o.x = chain5(vl6, vl7, v[0], v[1], v[2]);
-            o.y = chain5(v[0], v[1], v[2], v[3], v[4]);
-            o.z = chain5(v[2], v[3], v[4], v[5], v[6]);
-            o.w = chain5(v[4], v[5], v[6], v[7], vr0);
-            *reinterpret_cast<float4*>(out + (size_t)yo * opitch + (g.c >> 1)) = o;
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            if (yo + t < yo1)  // wave-uniform
+                reduce_row(w[2 * t], w[2 * t + 1], w[2 * t + 2], w[2 * t + 3], w[2 * t + 4], g, ob, (uint32_t)(yo + t) * orb);
         }
-        r0 = r2; r1 = r3; r2 = r4; r3 = n3; r4 = n4;
+        w[0] = w[2 * T]; w[1] = w[2 * T + 1]; w[2] = w[2 * T + 2];
+    }
+}
+
+// LDS-tiled form of the same kernel (S % 8 == 0): a 256-thread workgroup produces a 64 x 16 output
+// tile from a (2*16+3) x (2*64+8) input tile staged in LDS. Every thread issues its 4-5 16-byte
+// global loads back to back, so a CU with 5 resident workgroups keeps ~95 KiB outstanding and
+// finished workgroups are replaced one by one. Vertical pass: LDS tile -> LDS v-buffer (16-byte
+// reads, four columns per thread); horizontal pass: three 16-byte LDS reads -> four outputs ->
+// one 16-byte global store. Reflect-101 columns are register selects in the horizontal pass;
+// mirrored rows are resolved when the tile is loaded. Same arithmetic order as k_reduce_fast.
+constexpr int kTileW = 64, kTileH = 16;
+constexpr int kTileCols = 2 * kTileW + 8;   // input columns 2*x0 - 4 .. 2*x0 + 131
+constexpr int kTileRows = 2 * kTileH + 3;   // input rows    2*y0 - 2 .. 2*y0 + 32
+constexpr int kTileGroups = kTileCols / 4;  // 16-byte groups per tile row
+
+__global__ __launch_bounds__(256) void k_reduce_tiled(const float* __restrict__ in, float* __restrict__ out, int S, int pitch,
+                                                      size_t in_plane, int So, int opitch, size_t out_plane) {
+    __shared__ __attribute__((aligned(16))) float tile[kTileRows][kTileCols];
+    __shared__ __attribute__((aligned(16))) float vbuf[kTileH][kTileCols];  // column index = tile column - 2
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    const Buf ib = make_buf(in + (size_t)blockIdx.z * in_plane, in_plane * 4);
+    out += (size_t)blockIdx.z * out_plane;
+    const int hi = S - 1;
+    const int xin0 = 2 * x0 - 4;
+    // ---- stage the input tile -------------------------------------------------------------
+    constexpr int kSlots = kTileRows * kTileGroups;  // 35 * 34 = 1190
+    float4 ld[(kSlots + 255) / 256];
+#pragma unroll
+    for (int k = 0; k < (kSlots + 255) / 256; k++) {
+        const int slot = t + 256 * k;
+        const int r = slot / kTileGroups, g = slot - r * kTileGroups;
+        const int x = xin0 + 4 * g;
+        const int row = mirror_idx(min(2 * y0 - 2 + r, S + 1), hi);  // rows past the image feed unused outputs only
+        const uint32_t off = (slot < kSlots && x >= 0 && x < S) ? ((uint32_t)row * pitch + x) * 4u : kOob;
+        ld[k] = bload4(ib, off);
+    }
+#pragma unroll
+    for (int k = 0; k < (kSlots + 255) / 256; k++) {
+        const int slot = t + 256 * k;
+        const int r = slot / kTileGroups, g = slot - r * kTileGroups;
+        if (slot < kSlots) *reinterpret_cast<float4*>(&tile[r][4 * g]) = ld[k];
+    }
+    __syncthreads();
+    // ---- vertical pass: v(x, yo) = chain5 over tile rows 2*yo .. 2*yo + 4 ---------------------
+    constexpr int kVItems = kTileH * kTileGroups;  // 16 * 34 = 544
+#pragma unroll
+    for (int k = 0; k < (kVItems + 255) / 256; k++) {
+        const int item = t + 256 * k;
+        if (item < kVItems) {
+            const int yo = item / kTileGroups, g = item - yo * kTileGroups;
+            const float4 a = *reinterpret_cast<const float4*>(&tile[2 * yo][4 * g]);
+            const float4 b = *reinterpret_cast<const float4*>(&tile[2 * yo + 1][4 * g]);
+            const float4 c = *reinterpret_cast<const float4*>(&tile[2 * yo + 2][4 * g]);
+            const float4 d = *reinterpret_cast<const float4*>(&tile[2 * yo + 3][4 * g]);
+            const float4 e = *reinterpret_cast<const float4*>(&tile[2 * yo + 4][4 * g]);
+            const float v0 = chain5(a.x, b.x, c.x, d.x, e.x), v1 = chain5(a.y, b.y, c.y, d.y, e.y);
+            const float v2 = chain5(a.z, b.z, c.z, d.z, e.z), v3 = chain5(a.w, b.w, c.w, d.w, e.w);
+            // tile columns 4g .. 4g+3 land at v-buffer columns 4g-2 .. 4g+1 (two 8-byte stores)
+            if (g > 0) *reinterpret_cast<float2*>(&vbuf[yo][4 * g - 2]) = make_float2(v0, v1);
+            *reinterpret_cast<float2*>(&vbuf[yo][4 * g]) = make_float2(v2, v3);
+        }
+    }
+    __syncthreads();
+    // ---- horizontal pass: 4 outputs per thread --------------------------------------------------
+    const int yo = t >> 4, q = t & 15;
+    const int xo = x0 + 4 * q, yout = y0 + yo;
+    if (xo < So && yout < So) {
+        // v-buffer columns 8q .. 8q+11 hold input columns 2*xo - 2 .. 2*xo + 9
+        const float4 p0 = *reinterpret_cast<const float4*>(&vbuf[yo][8 * q]);
+        const float4 p1 = *reinterpret_cast<const float4*>(&vbuf[yo][8 * q + 4]);
+        const float4 p2 = *reinterpret_cast<const float4*>(&vbuf[yo][8 * q + 8]);
+        float m2 = p0.x, m1 = p0.y;                 // input columns 2*xo - 2, 2*xo - 1
+        const float c0 = p0.z, c1 = p0.w, c2 = p1.x, c3 = p1.y, c4 = p1.z, c5 = p1.w, c6 = p2.x, c7 = p2.y;
+        float c8 = p2.z;                            // input column 2*xo + 8
+        if (xo == 0) { m2 = c2; m1 = c1; }          // columns -2, -1 mirror onto 2, 1 (img_smooth.comp:13)
+        if (2 * xo + 8 >= S) c8 = c6;               // column S mirrors onto S - 2 (img_smooth.comp:12)
+        float4 o;
+        o.x = chain5(m2, m1, c0, c1, c2);
+        o.y = chain5(c0, c1, c2, c3, c4);
+        o.z = chain5(c2, c3, c4, c5, c6);
+        o.w = chain5(c4, c5, c6, c7, c8);
+        *reinterpret_cast<float4*>(out + (size_t)yout * opitch + xo) = o;
     }
 }
 
@@ -182,20 +287,11 @@ struct CRow {
     float hr;    // coarse column j0+4 (lane 63 with more image to its right)
 };
 
-__device__ __forceinline__ void load_crow(CRow& r, const float* __restrict__ base, int pitch, int row, const LaneCfg& g) {
-    const float* p = base + (size_t)row * pitch;
-    const int j0 = g.c >> 1;
-    if (g.active) {
-        float4 a = *reinterpret_cast<const float4*>(p + j0);
-        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    }
-    if (g.left_load) r.hl = p[j0 - 1];
-    if (g.right_load) r.hr = p[j0 + 4];
-}
-
-__device__ __forceinline__ void zero_crow(CRow& r) {
-    r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f;
-    r.hl = r.hr = 0.f;
+__device__ __forceinline__ void load_crow(CRow& r, const Buf& b, uint32_t row_off, const LaneCfg& g) {
+    const float4 a = bload4(b, g.coff + row_off);
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.hl = bload1(b, g.coff_l + row_off);
+    r.hr = bload1(b, g.coff_r + row_off);
 }
 
 // Horizontal pass for the 8 fine columns of a lane from its 4 coarse V values + neighbours; returns 4 * H.
@@ -238,17 +334,9 @@ __device__ __forceinline__ void lowpass_pair(const CRow& a, const CRow& b, const
     hpass8(Vo, l, r, lowO);
 }
 
-__device__ __forceinline__ void load8(float d[8], const float* __restrict__ p) {
-    float4 a = *reinterpret_cast<const float4*>(p);
-    float4 b = *reinterpret_cast<const float4*>(p + 4);
-    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
-}
-__device__ __forceinline__ void store8(float* __restrict__ p, const float d[8]) {
-    *reinterpret_cast<float4*>(p) = make_float4(d[0], d[1], d[2], d[3]);
-    *reinterpret_cast<float4*>(p + 4) = make_float4(d[4], d[5], d[6], d[7]);
-}
-
-// K7 + K8 + K9: band = fine - lowpass(coarse).  rows_per_wave counts COARSE rows (2 fine rows each).
+// K7 + K8 + K9: band = fine - lowpass(coarse). rows_per_wave counts COARSE rows (2 fine rows each);
+// T coarse rows per loop trip (T + 4T 16-byte loads per lane in flight).
+template <int T>
 __global__ __launch_bounds__(kBlockThreads) void k_band_fast(const float* __restrict__ fine, const float* __restrict__ coarse,
                                                              float* __restrict__ band, int S, int pitch, size_t plane,
                                                              int Sc, int cpitch, size_t cplane, int rows_per_wave) {
@@ -257,35 +345,39 @@ __global__ __launch_bounds__(kBlockThreads) void k_band_fast(const float* __rest
     const int k0 = seg * rows_per_wave;
     if (k0 >= Sc) return;
     const int k1 = min(k0 + rows_per_wave, Sc);
-    fine += (size_t)blockIdx.z * plane;
-    band += (size_t)blockIdx.z * plane;
-    coarse += (size_t)blockIdx.z * cplane;
+    const Buf fb = make_buf(fine + (size_t)blockIdx.z * plane, plane * 4);
+    const Buf bb = make_buf(band + (size_t)blockIdx.z * plane, plane * 4);
+    const Buf cb = make_buf(coarse + (size_t)blockIdx.z * cplane, cplane * 4);
     const LaneCfg g = make_cfg(blockIdx.x, lane, S);
+    const uint32_t rb = (uint32_t)pitch * 4u, crb = (uint32_t)cpitch * 4u;
 
-    CRow ca, cb, cc, cn;
-    zero_crow(ca); zero_crow(cb); zero_crow(cc); zero_crow(cn);
-    load_crow(ca, coarse, cpitch, coarse_of_fine(2 * k0 - 2, S), g);
-    load_crow(cb, coarse, cpitch, k0, g);
-    load_crow(cc, coarse, cpitch, coarse_of_fine(2 * k0 + 2, S), g);
-    for (int k = k0; k < k1; k++) {
-        if (k + 1 < k1) load_crow(cn, coarse, cpitch, coarse_of_fine(2 * k + 4, S), g);
-        float fe[8], fo[8];
-        if (g.active) {
-            load8(fe, fine + (size_t)(2 * k) * pitch + g.c);
-            load8(fo, fine + (size_t)(2 * k + 1) * pitch + g.c);
-        }
-        float lowE[8], lowO[8];
-        lowpass_pair(ca, cb, cc, g, lowE, lowO);
-        if (g.active) {
+    CRow cw[T + 2];  // coarse rows km1(k), k .. k+T-1, kp1(k+T-1)
+    load_crow(cw[0], cb, (uint32_t)coarse_of_fine(2 * k0 - 2, S) * crb, g);
+    load_crow(cw[1], cb, (uint32_t)k0 * crb, g);
+    for (int k = k0; k < k1; k += T) {
+        float fe[T][8], fo[T][8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                fe[j] = fe[j] - lowE[j];   // img_difference.comp:15
-                fo[j] = fo[j] - lowO[j];
-            }
-            store8(band + (size_t)(2 * k) * pitch + g.c, fe);
-            store8(band + (size_t)(2 * k + 1) * pitch + g.c, fo);
+        for (int t = 0; t < T; t++) {
+            const int ka = min(k + t, k1 - 1);
+            load_crow(cw[t + 2], cb, (uint32_t)coarse_of_fine(2 * ka + 2, S) * crb, g);
+            load8(fe[t], fb, g.off + (uint32_t)(2 * ka) * rb);
+            load8(fo[t], fb, g.off + (uint32_t)(2 * ka + 1) * rb);
         }
-        ca = cb; cb = cc; cc = cn;
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            if (k + t < k1) {  // wave-uniform
+                float lowE[8], lowO[8];
+                lowpass_pair(cw[t], cw[t + 1], cw[t + 2], g, lowE, lowO);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    fe[t][j] = fe[t][j] - lowE[j];   // img_difference.comp:15
+                    fo[t][j] = fo[t][j] - lowO[j];
+                }
+                store8(bb, g.off + (uint32_t)(2 * (k + t)) * rb, fe[t]);
+                store8(bb, g.off + (uint32_t)(2 * (k + t) + 1) * rb, fo[t]);
+            }
+        }
+        cw[0] = cw[T]; cw[1] = cw[T + 1];
     }
 }
 
@@ -351,14 +443,14 @@ template <int GAIN>
 __device__ __forceinline__ float gain_of(float s, float high, const CurveLds& t) {
     if (GAIN == GAIN_CONST) return high;
     if (GAIN == GAIN_RANGE) {
-        if (s == 0.0f) return high;                     // points[0].x == x
+        if (s == 0.0f) return high;                          // points[0].x == x
         if (s >= 0.0f && s <= 1.0f) return 0.0f * s + high;  // m = (high - high) / (1 - 0) = 0
         return 0.0f;
     }
     return curve_eval(t, s);
 }
 
-template <int GAIN, bool NR>
+template <int GAIN, bool NR, int T>
 __global__ __launch_bounds__(kBlockThreads) void k_expand_fast(ExpandArgs a) {
     __shared__ CurveLds tab;
     const int img = blockIdx.z;
@@ -371,72 +463,89 @@ __global__ __launch_bounds__(kBlockThreads) void k_expand_fast(ExpandArgs a) {
     const int k0 = seg * a.rows_per_wave;
     if (k0 >= a.Sc) return;
     const int k1 = min(k0 + a.rows_per_wave, a.Sc);
-    const float* band = a.band + (size_t)img * a.plane;
-    const float* sdev = (GAIN != GAIN_CONST) ? a.sdev + (size_t)img * a.plane : nullptr;
-    float* recon = a.recon + (size_t)img * a.plane;
-    const float* prev = a.prev + (size_t)img * a.cplane;
+    const int S = a.S;
+    const Buf bb = make_buf(a.band + (size_t)img * a.plane, a.plane * 4);
+    const Buf sb = make_buf((GAIN != GAIN_CONST ? a.sdev : a.band) + (size_t)img * a.plane, a.plane * 4);
+    const Buf ob = make_buf(a.recon + (size_t)img * a.plane, a.plane * 4);
+    const Buf pb = make_buf(a.prev + (size_t)img * a.cplane, a.cplane * 4);
     const float* cnr = NR ? a.cnr + (size_t)img * a.cnrPlane : nullptr;
-    const int S = a.S, pitch = a.pitch, cpitch = a.cpitch;
     const LaneCfg g = make_cfg(blockIdx.x, lane, S);
+    const uint32_t rb = (uint32_t)a.pitch * 4u, crb = (uint32_t)a.cpitch * 4u;
+    // noise reduction: the 8 columns of a lane share ceil(8 / scale) cnr texels per row
+    const int cxs[2] = {g.active ? g.c / a.cnrScale : 0, g.active ? (g.c + 4) / a.cnrScale : 0};
 
-    CRow ca, cb, cc, cn;
-    zero_crow(ca); zero_crow(cb); zero_crow(cc); zero_crow(cn);
-    load_crow(ca, prev, cpitch, coarse_of_fine(2 * k0 - 2, S), g);
-    load_crow(cb, prev, cpitch, k0, g);
-    load_crow(cc, prev, cpitch, coarse_of_fine(2 * k0 + 2, S), g);
-    for (int k = k0; k < k1; k++) {
-        if (k + 1 < k1) load_crow(cn, prev, cpitch, coarse_of_fine(2 * k + 4, S), g);
-        float be[8], bo[8], se[8], so[8];
-        if (g.active) {
-            load8(be, band + (size_t)(2 * k) * pitch + g.c);
-            load8(bo, band + (size_t)(2 * k + 1) * pitch + g.c);
-            if (GAIN != GAIN_CONST) {
-                load8(se, sdev + (size_t)(2 * k) * pitch + g.c);
-                load8(so, sdev + (size_t)(2 * k + 1) * pitch + g.c);
-            }
-        }
-        float lowE[8], lowO[8];
-        lowpass_pair(ca, cb, cc, g, lowE, lowO);
-        if (g.active) {
+    CRow cw[T + 2];
+    load_crow(cw[0], pb, (uint32_t)coarse_of_fine(2 * k0 - 2, S) * crb, g);
+    load_crow(cw[1], pb, (uint32_t)k0 * crb, g);
+    for (int k = k0; k < k1; k += T) {
+        float be[T][8], bo[T][8], se[T][8], so[T][8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                float pe = be[j] * gain_of<GAIN>(GAIN != GAIN_CONST ? se[j] : 0.0f, a.high, tab);  // contrast_curve_apply.comp:61
-                float po = bo[j] * gain_of<GAIN>(GAIN != GAIN_CONST ? so[j] : 0.0f, a.high, tab);
-                if (NR) {
-                    const int cx = (g.c + j) / a.cnrScale;                                       // noise_reduction.comp:39-45
-                    const float ce = cnr[(size_t)((2 * k) / a.cnrScale) * a.cnrPitch + cx] * kMaxCnrValue;
-                    const float co = cnr[(size_t)((2 * k + 1) / a.cnrScale) * a.cnrPitch + cx] * kMaxCnrValue;
-                    pe = pe * nr_factor(ce, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);     // noise_reduction.comp:57
-                    po = po * nr_factor(co, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
-                }
-                be[j] = lowE[j] + pe;   // img_addition.comp:15
-                bo[j] = lowO[j] + po;
+        for (int t = 0; t < T; t++) {
+            const int ka = min(k + t, k1 - 1);
+            load_crow(cw[t + 2], pb, (uint32_t)coarse_of_fine(2 * ka + 2, S) * crb, g);
+            load8(be[t], bb, g.off + (uint32_t)(2 * ka) * rb);
+            load8(bo[t], bb, g.off + (uint32_t)(2 * ka + 1) * rb);
+            if (GAIN != GAIN_CONST) {
+                load8(se[t], sb, g.off + (uint32_t)(2 * ka) * rb);
+                load8(so[t], sb, g.off + (uint32_t)(2 * ka + 1) * rb);
             }
-            store8(recon + (size_t)(2 * k) * pitch + g.c, be);
-            store8(recon + (size_t)(2 * k + 1) * pitch + g.c, bo);
         }
-        ca = cb; cb = cc; cc = cn;
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            if (k + t < k1) {  // wave-uniform
+                const int kk = k + t;
+                float lowE[8], lowO[8];
+                lowpass_pair(cw[t], cw[t + 1], cw[t + 2], g, lowE, lowO);
+                float fe[8], fo[8];  // noise-reduction factors of the two rows
+                if (NR) {
+                    const size_t re = (size_t)((2 * kk) / a.cnrScale) * a.cnrPitch, ro = (size_t)((2 * kk + 1) / a.cnrScale) * a.cnrPitch;
+                    if (a.cnrScale == 4 || a.cnrScale == 8) {  // columns c..c+3 and c+4..c+7 each sit inside one cnr texel (c % 8 == 0)
+                        const float e0 = nr_factor(cnr[re + cxs[0]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
+                        const float e1 = nr_factor(cnr[re + cxs[1]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
+                        const float o0 = nr_factor(cnr[ro + cxs[0]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
+                        const float o1 = nr_factor(cnr[ro + cxs[1]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
+#pragma unroll
+                        for (int j = 0; j < 8; j++) { fe[j] = j < 4 ? e0 : e1; fo[j] = j < 4 ? o0 : o1; }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const int cx = g.active ? (g.c + j) / a.cnrScale : 0;                 // noise_reduction.comp:39-45
+                            fe[j] = nr_factor(cnr[re + cx] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
+                            fo[j] = nr_factor(cnr[ro + cx] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    float pe = be[t][j] * gain_of<GAIN>(GAIN != GAIN_CONST ? se[t][j] : 0.0f, a.high, tab);  // contrast_curve_apply.comp:61
+                    float po = bo[t][j] * gain_of<GAIN>(GAIN != GAIN_CONST ? so[t][j] : 0.0f, a.high, tab);
+                    if (NR) {
+                        pe = pe * fe[j];   // noise_reduction.comp:57
+                        po = po * fo[j];
+                    }
+                    be[t][j] = lowE[j] + pe;   // img_addition.comp:15
+                    bo[t][j] = lowO[j] + po;
+                }
+                store8(ob, g.off + (uint32_t)(2 * kk) * rb, be[t]);
+                store8(ob, g.off + (uint32_t)(2 * kk + 1) * rb, bo[t]);
+            }
+        }
+        cw[0] = cw[T]; cw[1] = cw[T + 1];
     }
 }
 
-template <int GAIN, bool NR>
-__global__ void k_expand_generic(ExpandArgs a) {
-    __shared__ CurveLds tab;
-    const int img = blockIdx.z;
-    if (GAIN == GAIN_CURVE) {
-        const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-        const DevCurve* src = a.curves + (size_t)img * a.curve_stride;
-        for (int i = tid; i < kCurveCap; i += blockDim.x * blockDim.y) {
-            tab.x[i] = src->x[i]; tab.y[i] = src->y[i]; tab.m[i] = src->m[i];
-        }
-        if (tid == 0) { tab.count = src->count; tab.monotone = src->monotone; }
-        __syncthreads();
+__device__ __forceinline__ void curve_to_lds_2d(CurveLds& tab, const DevCurve* __restrict__ src) {
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    for (int i = tid; i < kCurveCap; i += blockDim.x * blockDim.y) {
+        tab.x[i] = src->x[i]; tab.y[i] = src->y[i]; tab.m[i] = src->m[i];
     }
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= a.S || y >= a.S) return;
+    if (tid == 0) { tab.count = src->count; tab.monotone = src->monotone; }
+}
+
+// band * gain [* nr] at one texel (generic form)
+template <int GAIN, bool NR>
+__device__ __forceinline__ float exp_band_at(const ExpandArgs& a, const CurveLds& tab, int img, int x, int y) {
     const size_t o = (size_t)img * a.plane + (size_t)y * a.pitch + x;
-    const float low = lowpass_generic(a.prev + (size_t)img * a.cplane, a.cpitch, a.Sc, a.S, x, y);
     const float s = (GAIN != GAIN_CONST) ? a.sdev[o] : 0.0f;
     float p = a.band[o] * gain_of<GAIN>(s, a.high, tab);
     if (NR) {
@@ -444,7 +553,22 @@ __global__ void k_expand_generic(ExpandArgs a) {
         const float c = ((cx < a.cnrS && cy < a.cnrS) ? a.cnr[(size_t)img * a.cnrPlane + (size_t)cy * a.cnrPitch + cx] : 0.0f) * kMaxCnrValue;
         p = p * nr_factor(c, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
     }
-    a.recon[o] = low + p;
+    return p;
+}
+
+template <int GAIN, bool NR>
+__global__ void k_expand_generic(ExpandArgs a) {
+    __shared__ CurveLds tab;
+    const int img = blockIdx.z;
+    if (GAIN == GAIN_CURVE) {
+        curve_to_lds_2d(tab, a.curves + (size_t)img * a.curve_stride);
+        __syncthreads();
+    }
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= a.S || y >= a.S) return;
+    const float low = lowpass_generic(a.prev + (size_t)img * a.cplane, a.cpitch, a.Sc, a.S, x, y);
+    a.recon[(size_t)img * a.plane + (size_t)y * a.pitch + x] = low + exp_band_at<GAIN, NR>(a, tab, img, x, y);
 }
 
 // band after contrast curve (+ noise reduction): what img_addition.comp reads as inputImageB
@@ -454,26 +578,13 @@ __global__ void k_exp_band_generic(ExpandArgs a) {
     __shared__ CurveLds tab;
     const int img = blockIdx.z;
     if (GAIN == GAIN_CURVE) {
-        const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-        const DevCurve* src = a.curves + (size_t)img * a.curve_stride;
-        for (int i = tid; i < kCurveCap; i += blockDim.x * blockDim.y) {
-            tab.x[i] = src->x[i]; tab.y[i] = src->y[i]; tab.m[i] = src->m[i];
-        }
-        if (tid == 0) { tab.count = src->count; tab.monotone = src->monotone; }
+        curve_to_lds_2d(tab, a.curves + (size_t)img * a.curve_stride);
         __syncthreads();
     }
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= a.S || y >= a.S) return;
-    const size_t o = (size_t)img * a.plane + (size_t)y * a.pitch + x;
-    const float s = (GAIN != GAIN_CONST) ? a.sdev[o] : 0.0f;
-    float p = a.band[o] * gain_of<GAIN>(s, a.high, tab);
-    if (NR) {
-        const int cx = x / a.cnrScale, cy = y / a.cnrScale;
-        const float c = ((cx < a.cnrS && cy < a.cnrS) ? a.cnr[(size_t)img * a.cnrPlane + (size_t)cy * a.cnrPitch + cx] : 0.0f) * kMaxCnrValue;
-        p = p * nr_factor(c, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
-    }
-    a.recon[o] = p;
+    a.recon[(size_t)img * a.plane + (size_t)y * a.pitch + x] = exp_band_at<GAIN, NR>(a, tab, img, x, y);
 }
 
 // ======================================================================================
@@ -490,11 +601,20 @@ static const dim3 kGenericBlock(32, 8, 1);
 
 static inline bool fast_ok(int S) { return S >= 8 && (S % 8) == 0; }
 
+// rows_per_trip: 0 selects the LDS-tiled kernel, 1 / 2 / 4 the streaming kernel with that many rows per trip
 void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch,
-                   int rows_per_wave, bool force_generic) {
-    if (fast_ok(li.S) && !force_generic) {
-        hipLaunchKernelGGL(k_reduce_fast, stream_grid(li.S, lo.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, in, out,
-                           li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
+                   int rows_per_wave, bool force_generic, int rows_per_trip) {
+    if (fast_ok(li.S) && !force_generic && rows_per_trip == 0) {
+        hipLaunchKernelGGL(k_reduce_tiled, dim3((lo.S + kTileW - 1) / kTileW, (lo.S + kTileH - 1) / kTileH, batch), dim3(256), 0, st, in, out,
+                           li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane);
+    } else if (fast_ok(li.S) && !force_generic) {
+        const dim3 grid = stream_grid(li.S, lo.S, rows_per_wave, batch);
+        if (rows_per_trip >= 4)
+            hipLaunchKernelGGL(k_reduce_fast<4>, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
+        else if (rows_per_trip >= 2)
+            hipLaunchKernelGGL(k_reduce_fast<2>, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
+        else
+            hipLaunchKernelGGL(k_reduce_fast<1>, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
     } else {
         hipLaunchKernelGGL(k_reduce_generic, generic_grid(lo.S, batch), kGenericBlock, 0, st, in, out, li.S, li.pitch,
                            li.plane, lo.S, lo.pitch, lo.plane);
@@ -502,10 +622,13 @@ void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* 
 }
 
 void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc,
-                 int batch, int rows_per_wave, bool force_generic) {
+                 int batch, int rows_per_wave, bool force_generic, int rows_per_trip) {
     if (fast_ok(lf.S) && !force_generic) {
-        hipLaunchKernelGGL(k_band_fast, stream_grid(lf.S, lc.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, fine, coarse,
-                           band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave);
+        const dim3 grid = stream_grid(lf.S, lc.S, rows_per_wave, batch);
+        if (rows_per_trip >= 2)
+            hipLaunchKernelGGL(k_band_fast<2>, grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave);
+        else
+            hipLaunchKernelGGL(k_band_fast<1>, grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave);
     } else {
         hipLaunchKernelGGL(k_band_generic, generic_grid(lf.S, batch), kGenericBlock, 0, st, fine, coarse, band, lf.S, lf.pitch,
                            lf.plane, lc.S, lc.pitch, lc.plane);
@@ -518,19 +641,21 @@ void launch_lowpass(hipStream_t st, const float* coarse, float* low, const Level
 }
 
 template <int GAIN, bool NR>
-static void launch_expand_t(hipStream_t st, const ExpandArgs& a, int batch, bool force_generic) {
+static void launch_expand_t(hipStream_t st, const ExpandArgs& a, int batch, bool force_generic, int rows_per_trip) {
     if (fast_ok(a.S) && !force_generic) {
-        hipLaunchKernelGGL((k_expand_fast<GAIN, NR>), stream_grid(a.S, a.Sc, a.rows_per_wave, batch), dim3(kBlockThreads), 0, st, a);
+        const dim3 grid = stream_grid(a.S, a.Sc, a.rows_per_wave, batch);
+        if (rows_per_trip >= 2) hipLaunchKernelGGL((k_expand_fast<GAIN, NR, 2>), grid, dim3(kBlockThreads), 0, st, a);
+        else hipLaunchKernelGGL((k_expand_fast<GAIN, NR, 1>), grid, dim3(kBlockThreads), 0, st, a);
     } else {
         hipLaunchKernelGGL((k_expand_generic<GAIN, NR>), generic_grid(a.S, batch), kGenericBlock, 0, st, a);
     }
 }
 
-void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic) {
-    if (gain_mode == GAIN_CONST) launch_expand_t<GAIN_CONST, false>(st, a, batch, force_generic);
-    else if (gain_mode == GAIN_RANGE) launch_expand_t<GAIN_RANGE, false>(st, a, batch, force_generic);
-    else if (nr) launch_expand_t<GAIN_CURVE, true>(st, a, batch, force_generic);
-    else launch_expand_t<GAIN_CURVE, false>(st, a, batch, force_generic);
+void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic, int rows_per_trip) {
+    if (gain_mode == GAIN_CONST) launch_expand_t<GAIN_CONST, false>(st, a, batch, force_generic, rows_per_trip);
+    else if (gain_mode == GAIN_RANGE) launch_expand_t<GAIN_RANGE, false>(st, a, batch, force_generic, rows_per_trip);
+    else if (nr) launch_expand_t<GAIN_CURVE, true>(st, a, batch, force_generic, rows_per_trip);
+    else launch_expand_t<GAIN_CURVE, false>(st, a, batch, force_generic, rows_per_trip);
 }
 
 void launch_exp_band(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch) {

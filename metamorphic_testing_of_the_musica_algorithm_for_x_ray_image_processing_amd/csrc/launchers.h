@@ -44,10 +44,10 @@ struct GradArgs {
 };
 
 // kernels_pyramid.hip
-void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave, bool force_generic);
-void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave, bool force_generic);
+void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave, bool force_generic, int rows_per_trip);
+void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave, bool force_generic, int rows_per_trip);
 void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch);
-void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic);
+void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic, int rows_per_trip);
 void launch_exp_band(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch);
 // kernels_analysis.hip
 void launch_clear(hipStream_t st, uint32_t* minmax, uint32_t* noise_hist, uint32_t* grad_hist, uint32_t* clahe_hist, int batch);
@@ -58,7 +58,9 @@ void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const Leve
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch);
 void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves, const musica_contrast_params* cparams, int levels, int batch);
 void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& l3, const musica_hist_max_point* maxpts, int levels, int batch);
-void launch_sum_image(hipStream_t st, const float* img, const LevelDesc& l, double* out, int batch);
+void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact,
+                  const musica_hist_max_point* noise_max, int levels, const musica_hist_max_point* grad_max, const DevCurve* gcurve,
+                  musica_stats* out, uint32_t image_id_base, int batch);
 // kernels_gradation.hip
 void launch_grad_hist(hipStream_t st, const GradArgs& a, int batch);
 void launch_grad_hist_ref(hipStream_t st, const float* img, const float* relevant, const LevelDesc& l0, uint32_t* hist, int batch);

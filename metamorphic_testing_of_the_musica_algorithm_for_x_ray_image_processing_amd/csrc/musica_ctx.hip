@@ -71,7 +71,7 @@ struct musica_ctx {
     DevCurve* d_gcurve;
     float* d_graded;
     float* d_scratch;
-    double* d_sum;
+    musica_stats* d_stats;
     uint32_t* d_clahe_hist;
     musica_point* d_clahe_pts;
     float* d_clahe_graded;
@@ -79,9 +79,9 @@ struct musica_ctx {
     musica_contrast_params h_cparams[MUSICA_MAX_LEVELS];
     musica_nr_params h_nr[3];
     // tunables
-    int reduce_rows, band_rows, expand_rows, sdev_rows, grad_groups;
+    int reduce_rows, band_rows, expand_rows, sdev_rows, grad_groups, reduce_trip, band_trip, expand_trip, min_waves;
     // profiling
-    bool profiling;
+    uint32_t profiling;  // bit i set: bracket kernel family i with HIP events
     std::vector<ProfSpan> spans;
     size_t spans_used;
     double prof_total_us[MUSICA_KERNEL_COUNT];
@@ -134,12 +134,13 @@ static musica_nr_params host_nr_params(uint32_t i) {
 
 static uint32_t cnr_scale(int S, int cnrS) { return (uint32_t)ceilf((float)S / (float)cnrS); }  // noise_reduction.comp:38
 
+static int g_min_waves = 2048;
 static int pick_rows(int dflt, int min_rows, int S, int rows_total, int batch) {
     int rpw = dflt;
     const int strips = (S + kStripCols - 1) / kStripCols;
     while (rpw > min_rows) {
         const long waves = (long)strips * ((rows_total + rpw - 1) / rpw) * batch;
-        if (waves >= 2048) break;
+        if (waves >= g_min_waves) break;
         rpw /= 2;
     }
     return rpw < min_rows ? min_rows : rpw;
@@ -190,7 +191,7 @@ musica_ctx* musica_create(const musica_params* params) {
     c->N = (int)N; c->L = (int)L; c->B = params->batch ? (int)params->batch : 1;
     c->p.levels = L; c->p.batch = (uint32_t)c->B;
     c->generic = (params->flags & MUSICA_FLAG_GENERIC_KERNELS) != 0;
-    c->stream = nullptr; c->profiling = false; c->spans_used = 0; c->cur_input = nullptr;
+    c->stream = nullptr; c->profiling = 0; c->spans_used = 0; c->cur_input = nullptr;
     memset(c->prof_total_us, 0, sizeof(c->prof_total_us));
     memset(c->prof_count, 0, sizeof(c->prof_count));
     int s = (int)N;
@@ -205,10 +206,15 @@ musica_ctx* musica_create(const musica_params* params) {
     for (int i = 0; i < c->L; i++) c->h_cparams[i] = host_contrast_params((uint32_t)i, L);
     for (int i = 0; i < 3; i++) c->h_nr[i] = host_nr_params((uint32_t)i);
     c->reduce_rows = env_int("MUSICA_REDUCE_ROWS", 16);
+    c->reduce_trip = env_int("MUSICA_REDUCE_TRIP", 1);
+    c->band_trip = env_int("MUSICA_BAND_TRIP", 2);
+    c->expand_trip = env_int("MUSICA_EXPAND_TRIP", 2);
+    c->min_waves = env_int("MUSICA_MIN_WAVES", 4096);
     c->band_rows = env_int("MUSICA_BAND_ROWS", 8);
     c->expand_rows = env_int("MUSICA_EXPAND_ROWS", 8);
     c->sdev_rows = env_int("MUSICA_SDEV_ROWS", 32) & ~15;
     if (c->sdev_rows < 16) c->sdev_rows = 16;
+    g_min_waves = c->min_waves;
     c->grad_groups = env_int("MUSICA_GRAD_GROUPS", 1);
     if (c->grad_groups < 1) c->grad_groups = 1;
 
@@ -233,7 +239,7 @@ musica_ctx* musica_create(const musica_params* params) {
     ok = ok && dalloc(c, &c->d_gcurve, B);
     ok = ok && dalloc(c, &c->d_graded, B * c->lv[0].plane);
     ok = ok && dalloc(c, &c->d_scratch, B * c->lv[0].plane);
-    ok = ok && dalloc(c, &c->d_sum, B);
+    ok = ok && dalloc(c, &c->d_stats, B);
     c->d_clahe_hist = nullptr; c->d_clahe_pts = nullptr; c->d_clahe_graded = nullptr;
     if (ok && (params->flags & MUSICA_FLAG_CLAHE)) {
         const size_t tb = MUSICA_CLAHE_TILES * MUSICA_CLAHE_TILES * MUSICA_CLAHE_BINS;
@@ -263,7 +269,7 @@ struct Span {
     musica_ctx* c;
     ProfSpan* s;
     Span(musica_ctx* ctx, int id) : c(ctx), s(nullptr) {
-        if (!c->profiling) return;
+        if (!((c->profiling >> id) & 1u)) return;
         if (c->spans_used == c->spans.size()) {
             ProfSpan n;
             n.id = id;
@@ -307,11 +313,11 @@ static void enqueue_reduce(musica_ctx* c) {
         const LevelDesc& lc = c->lv[i + 1];
         {
             Span sp(c, i == 0 ? MUSICA_KERNEL_REDUCE_L0 : MUSICA_KERNEL_REDUCE_REST);
-            launch_reduce(c->stream, level_input(c, i), lf, c->d_down[i], lc, c->B, pick_rows(c->reduce_rows, 4, lf.S, lc.S, c->B), c->generic);
+            launch_reduce(c->stream, level_input(c, i), lf, c->d_down[i], lc, c->B, pick_rows(c->reduce_rows, 1, lf.S, lc.S, c->B), c->generic, c->reduce_trip);
         }
         {
             Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST);
-            launch_band(c->stream, level_input(c, i), c->d_down[i], c->d_band[i], lf, lc, c->B, pick_rows(c->band_rows, 2, lf.S, lc.S, c->B), c->generic);
+            launch_band(c->stream, level_input(c, i), c->d_down[i], c->d_band[i], lf, lc, c->B, pick_rows(c->band_rows, 1, lf.S, lc.S, c->B), c->generic, c->band_trip);
         }
     }
 }
@@ -352,7 +358,7 @@ static ExpandArgs expand_args(musica_ctx* c, int lvl, float* dst) {
     a.high = c->h_cparams[lvl].highContrastFactor;
     const musica_nr_params& q = c->h_nr[lvl < 3 ? lvl : 0];
     a.lowCnr = q.lowCnr; a.lowFactor = q.lowFactor; a.highCnr = q.highCnr; a.highFactor = q.highFactor;
-    a.rows_per_wave = pick_rows(c->expand_rows, 2, lf.S, lc.S, c->B);
+    a.rows_per_wave = pick_rows(c->expand_rows, 1, lf.S, lc.S, c->B);
     return a;
 }
 static int gain_mode(int lvl) { return lvl > MUSICA_CNR_LEVEL ? GAIN_CONST : (lvl == MUSICA_CNR_LEVEL ? GAIN_RANGE : GAIN_CURVE); }
@@ -363,7 +369,7 @@ static void enqueue_expand(musica_ctx* c) {
     for (int lvl = c->L - 1; lvl >= 0; lvl--) {
         Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
         const ExpandArgs a = expand_args(c, lvl, c->d_recon[lvl]);
-        launch_expand(c->stream, a, gain_mode(lvl), uses_nr(lvl), c->B, c->generic);
+        launch_expand(c->stream, a, gain_mode(lvl), uses_nr(lvl), c->B, c->generic, c->expand_trip);
     }
 }
 
@@ -660,30 +666,19 @@ int musica_get_minmax(musica_ctx* c, uint32_t idx, float* min_sqrt, float* max_s
     *min_sqrt = c->min_chain_exact ? (float)(uint32_t)mn : 0.0f;
     return 1;
 }
+int musica_stats_device(musica_ctx* c, void* d_dst, uint32_t image_id_base) {
+    CHECK_CTX(c);
+    if (!d_dst) return fail("musica_stats_device: d_dst is NULL");
+    launch_stats(c->stream, c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_noise_max, c->L, c->d_grad_max,
+                 c->d_gcurve, (musica_stats*)d_dst, image_id_base, c->B);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e));
+    return 1;
+}
 int musica_get_stats(musica_ctx* c, uint32_t idx, musica_stats* dst) {
     CHECK_CTX(c); CHECK_IMG(c, idx);
-    memset(dst, 0, sizeof(*dst));
-    dst->image_id = idx;
-    if (!musica_get_minmax(c, idx, &dst->min_sqrt, &dst->max_sqrt)) return 0;
-    for (uint32_t l = 0; l < 4; l++) {
-        musica_hist_max_point mp;
-        if (!musica_get_noise_hist_max(c, idx, l, &mp)) return 0;
-        dst->noise_max_bin[l] = mp.maxBin;
-        dst->noise_max_value[l] = mp.maxValue;
-    }
-    musica_hist_max_point gm;
-    if (!musica_get_grad_hist_max(c, idx, &gm)) return 0;
-    dst->grad_max_bin = gm.maxBin;
-    dst->grad_max_value = gm.maxValue;
-    const LevelDesc& l3 = c->lv[MUSICA_CNR_LEVEL];
-    launch_sum_image(c->stream, c->d_cnr, l3, c->d_sum, c->B);
-    double sum = 0.0;
-    if (!download_small(c, c->d_sum + idx, &sum, 1)) return 0;
-    dst->mean_cnr = (float)(sum / ((double)l3.S * l3.S) * 256.0);
-    DevCurve dc;
-    if (!download_small(c, c->d_gcurve + idx, &dc, 1)) return 0;
-    dst->t0 = dc.t0; dst->ta = dc.ta; dst->t1 = dc.t1;
-    return 1;
+    if (!musica_stats_device(c, c->d_stats, 0)) return 0;
+    return download_small(c, c->d_stats + idx, dst, 1);
 }
 int musica_get_clahe_hist(musica_ctx* c, uint32_t idx, uint32_t* dst) {
     CHECK_CTX(c); CHECK_IMG(c, idx);
@@ -778,7 +773,7 @@ int musica_profile_enable(musica_ctx* c, int enabled) {
     CHECK_CTX(c);
     HIP_OK(hipStreamSynchronize(c->stream));
     collect_spans(c);
-    c->profiling = enabled != 0;
+    c->profiling = enabled < 0 ? 0xFFFFFFFFu : (uint32_t)enabled;  // < 0: every kernel family; else bit i = musica_kernel_id i
     return 1;
 }
 int musica_profile_reset(musica_ctx* c) {
@@ -811,7 +806,7 @@ int musica_k_reduce(musica_ctx* c, const float* d_in, uint32_t side, uint32_t in
     CHECK_CTX(c);
     LevelDesc li, lo;
     if (!reduce_descs(side, in_pitch, out_pitch, &li, &lo)) return 0;
-    launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, pick_rows(c->reduce_rows, 4, li.S, lo.S, (int)batch), c->generic);
+    launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, pick_rows(c->reduce_rows, 1, li.S, lo.S, (int)batch), c->generic, c->reduce_trip);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e));
     return 1;
@@ -823,12 +818,12 @@ int musica_k_reduce_timed(musica_ctx* c, const float* d_in, uint32_t side, uint3
     LevelDesc li, lo;
     if (!reduce_descs(side, in_pitch, out_pitch, &li, &lo)) return 0;
     if (iters < 1) iters = 1;
-    const int rpw = pick_rows(c->reduce_rows, 4, li.S, lo.S, (int)batch);
+    const int rpw = pick_rows(c->reduce_rows, 1, li.S, lo.S, (int)batch);
     hipEvent_t a, b;
     HIP_OK(hipEventCreate(&a));
     HIP_OK(hipEventCreate(&b));
     HIP_OK(hipEventRecord(a, c->stream));
-    for (uint32_t i = 0; i < iters; i++) launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, rpw, c->generic);
+    for (uint32_t i = 0; i < iters; i++) launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, rpw, c->generic, c->reduce_trip);
     HIP_OK(hipEventRecord(b, c->stream));
     HIP_OK(hipEventSynchronize(b));
     float ms = 0.f;

@@ -118,6 +118,7 @@ ABI = {
     "musica_get_nr_params": (C.c_int, [_VP, C.c_uint32, C.POINTER(NrParams)]),
     "musica_get_minmax": (C.c_int, [_VP, C.c_uint32, _F32P, _F32P]),
     "musica_get_stats": (C.c_int, [_VP, C.c_uint32, C.POINTER(Stats)]),
+    "musica_stats_device": (C.c_int, [_VP, _VP, C.c_uint32]),
     "musica_get_clahe_hist": (C.c_int, [_VP, C.c_uint32, _U32P]),
     "musica_get_clahe_curves": (C.c_int, [_VP, C.c_uint32, C.POINTER(Point)]),
     "musica_debug_process": (C.c_int, [_VP, C.c_uint32, C.c_char_p]),
@@ -333,6 +334,10 @@ class MusicaProcessing:
         self._ok(self._lib.musica_get_stats(self._h, image_index, C.byref(s)), "musica_get_stats")
         return s
 
+    def stats_device(self, d_dst, image_id_base=0):
+        """Write batch x musica_stats into caller-owned device memory (async on the ctx stream)."""
+        self._ok(self._lib.musica_stats_device(self._h, d_dst, image_id_base), "musica_stats_device")
+
     def clahe_hist(self, image_index=0):
         out = np.empty((4, 4, 256), dtype=np.uint32)
         self._ok(self._lib.musica_get_clahe_hist(self._h, image_index, out.ctypes.data_as(_U32P)), "musica_get_clahe_hist")
@@ -344,8 +349,17 @@ class MusicaProcessing:
         return out
 
     # ---- profiling ----------------------------------------------------------------------
-    def profile_enable(self, enabled=True):
-        self._ok(self._lib.musica_profile_enable(self._h, 1 if enabled else 0), "musica_profile_enable")
+    def profile_enable(self, which=True):
+        """True: every kernel family; False: off; a list of kernel names: only those families."""
+        if which is True:
+            mask = -1
+        elif not which:
+            mask = 0
+        else:
+            mask = 0
+            for name in which:
+                mask |= 1 << KERNEL_ID[name]
+        self._ok(self._lib.musica_profile_enable(self._h, mask), "musica_profile_enable")
 
     def profile_reset(self):
         self._ok(self._lib.musica_profile_reset(self._h), "musica_profile_reset")
