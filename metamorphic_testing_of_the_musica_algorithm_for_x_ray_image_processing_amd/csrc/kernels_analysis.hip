@@ -7,6 +7,7 @@
 //   k_noise_curves  : img_histogram_max.comp + contrast_curve_generate.comp                 (K12 + K13)
 //   k_cnr           : img_cnr.comp                                                          (K15)
 //   k_sqrt          : img_sqrt.comp alone (debug image)
+#include <stdlib.h>
 #include <algorithm>
 #include "kernels_common.h"
 #include "launchers.h"
@@ -14,13 +15,14 @@
 namespace musica {
 
 // ---- clears ---------------------------------------------------------------------------
-// minmax[b] = {min = 0xFFFFFFFF, max = 0}; noise_hist[b][4][2048] = 0; grad_hist[b][1024] = 0; clahe hist = 0.
+// minmax[b] = {min = 0xFFFFFFFF at word 0, max = 0 at word kMaxWord} (one 64-byte line each: the atomics of different
+// images and of min / max then go to different L2 channels); noise_hist[b][4][2048] = 0; grad_hist[b][1024] = 0; clahe hist = 0.
 __global__ void k_clear(uint32_t* __restrict__ minmax, uint32_t* __restrict__ noise_hist, uint32_t* __restrict__ grad_hist,
                         uint32_t* __restrict__ clahe_hist, int batch) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int nh = batch * 4 * MUSICA_NOISE_BINS, gh = batch * MUSICA_GRAD_BINS;
     const int ch = clahe_hist ? batch * MUSICA_CLAHE_TILES * MUSICA_CLAHE_TILES * MUSICA_CLAHE_BINS : 0;
-    if (minmax && i < batch) { minmax[2 * i] = 0xFFFFFFFFu; minmax[2 * i + 1] = 0u; }
+    if (minmax && i < batch) { minmax[kMinMaxStride * i] = 0xFFFFFFFFu; minmax[kMinMaxStride * i + kMaxWord] = 0u; }
     if (noise_hist && i < nh) noise_hist[i] = 0u;
     if (grad_hist && i < gh) grad_hist[i] = 0u;
     if (i < ch) clahe_hist[i] = 0u;
@@ -73,14 +75,14 @@ __global__ __launch_bounds__(256) void k_minmax_u16(const uint16_t* __restrict__
     if (threadIdx.x == 0) {
         mn = min(min(smn[0], smn[1]), min(smn[2], smn[3]));
         mx = max(max(smx[0], smx[1]), max(smx[2], smx[3]));
-        atomicMin(&minmax[2 * blockIdx.z], mn);
-        atomicMax(&minmax[2 * blockIdx.z + 1], mx);
+        atomicMin(&minmax[kMinMaxStride * blockIdx.z], mn);
+        atomicMax(&minmax[kMinMaxStride * blockIdx.z + kMaxWord], mx);
     }
 }
 
 // The two scalars img_normalize.comp:17-18 reads from the 1x1 ends of the chains.
 __device__ __forceinline__ void chain_scalars(const uint32_t* __restrict__ minmax, int img, int min_chain_exact, float& minv, float& maxv) {
-    const uint32_t mnu = minmax[2 * img], mxu = minmax[2 * img + 1];
+    const uint32_t mnu = minmax[kMinMaxStride * img], mxu = minmax[kMinMaxStride * img + kMaxWord];
     maxv = (float)f2u(sqrtf((float)mxu));
     minv = min_chain_exact ? (float)f2u(sqrtf((float)mnu)) : 0.0f;
 }
@@ -200,6 +202,7 @@ __device__ __forceinline__ float sum5(float a, float b, float c, float d, float 
 }
 
 // One output row of sdev from its five rows of squares + the histogram scan of that row.
+template <bool HIST>
 __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const SRow& r2, const SRow& r3, const SRow& r4, const SCfg& g, int S,
                                          int y, int cov, float* __restrict__ drow, uint32_t* lh, uint32_t& alive) {
     float q[8];
@@ -233,7 +236,7 @@ __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const S
     }
     // noise_hist.comp:20-47
     if ((y & (kHistArea - 1)) == 0) alive = 0xFFu;
-    if (y < cov) {
+    if (HIST && y < cov) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             if (!(alive & (1u << j))) continue;
@@ -258,7 +261,7 @@ __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const S
 // rows_per_wave must be a multiple of 16 (histogram runs start at y % 16 == 0) and of T.
 // cov = (imageSize / 512) * 512: the part of the grid the reference's dispatch covers (src/vk_processing.cpp:2293-2295).
 // T rows per loop trip: the T new rows are loaded back to back before any arithmetic.
-template <int T>
+template <int T, bool HIST>
 __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
                                                              size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov,
                                                              int rows_per_wave) {
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist(const float* __rest
 #pragma unroll
             for (int t = 0; t < T; t++) {
                 if (y + t < y1)  // wave-uniform
-                    sdev_row(w[t], w[t + 1], w[t + 2], w[t + 3], w[t + 4], g, S, y + t, cov, sdev + (size_t)(y + t) * pitch, lh, alive);
+                    sdev_row<HIST>(w[t], w[t + 1], w[t + 2], w[t + 3], w[t + 4], g, S, y + t, cov, sdev + (size_t)(y + t) * pitch, lh, alive);
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) w[i] = w[T + i];
@@ -357,8 +360,12 @@ __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long k
 // level then builds its contrast curve (src/vk_processing.cpp:2284-2320).
 __global__ __launch_bounds__(256) void k_noise_curves(const uint32_t* __restrict__ hist, size_t hist_stride,
                                                       musica_hist_max_point* __restrict__ maxpts, DevCurve* __restrict__ curves,
-                                                      const musica_contrast_params* __restrict__ cparams, int levels) {
+                                                      const musica_contrast_params* __restrict__ cparams, int levels,
+                                                      DevCurveLut* __restrict__ luts) {
     __shared__ unsigned long long scratch[16];
+    __shared__ float sx[kCurveCap];
+    __shared__ int sbucket[kCurveCap];
+    __shared__ int sok;
     const int level = blockIdx.x, img = blockIdx.y;
     musica_hist_max_point mp;
     mp.maxValue = 0; mp.maxBin = 0;
@@ -372,9 +379,9 @@ __global__ __launch_bounds__(256) void k_noise_curves(const uint32_t* __restrict
         k = block_max_u64(k, scratch);
         if (k) { mp.maxValue = (uint32_t)(k >> 32); mp.maxBin = 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull); }
     }
-    if (threadIdx.x != 0) return;
-    maxpts[(size_t)img * levels + level] = mp;
     DevCurve* c = curves + (size_t)img * levels + level;
+    if (threadIdx.x == 0) {
+    maxpts[(size_t)img * levels + level] = mp;
     const float low = cparams[level].lowContrastFactor, high = cparams[level].highContrastFactor;
     uint32_t n = 0;
     if (low == 1.0f) {                                                                      // contrast_curve_generate.comp:59
@@ -390,6 +397,48 @@ __global__ __launch_bounds__(256) void k_noise_curves(const uint32_t* __restrict
     c->count = n;
     c->t0 = c->ta = c->t1 = 0.0f;
     curve_finish(c);
+    }
+    if (level >= MUSICA_COARSER_LEVELS_START) return;   // only the 33-point curves get a lookup table (block-uniform)
+    __syncthreads();                                    // thread 0's curve is visible to the block
+    // ---- bucket table for the expand kernel (see DevCurveLut) ----
+    DevCurveLut* lut = luts + (size_t)img * MUSICA_COARSER_LEVELS_START + level;
+    const int count = (int)c->count;
+    const float range = c->x[kLutTailFirst - 1] * 1.25f;              // 1.75 p: above x[22] = 1.4 p, below x[23] >= 1.49 p + 0.01
+    const float inv_w = (float)kLutBuckets / range;
+    if (threadIdx.x == 0) sok = (c->monotone && count == 33 && range > 0.0f && inv_w < 3.0e38f) ? 1 : 0;
+    if ((int)threadIdx.x < kCurveCap) {
+        const float x = c->x[threadIdx.x];
+        sx[threadIdx.x] = x;
+        const float kf = x * inv_w;
+        sbucket[threadIdx.x] = ((int)threadIdx.x < count && kf < (float)kLutBuckets) ? (int)kf : kLutBuckets;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < count) {   // the table covers exactly the abscissae 0..22
+        const bool inside = sbucket[threadIdx.x] < kLutBuckets;
+        if (inside != ((int)threadIdx.x < kLutTailFirst)) sok = 0;
+    }
+    {
+        const int k = threadIdx.x;    // one thread per bucket (blockDim.x == kLutBuckets)
+        int jlo = 0, inb = 0;
+        float xa = __builtin_huge_valf(), xb = __builtin_huge_valf();
+        for (int i = 0; i < count && i < kCurveCap; i++) {
+            const int b = sbucket[i];
+            if (b < k) jlo++;
+            else if (b == k) {
+                if (inb == 0) xa = sx[i];
+                else if (inb == 1) xb = sx[i];
+                inb++;
+            }
+        }
+        if (inb > 2) sok = 0;
+        lut->bucket[k] = make_float4((float)jlo, xa, xb, 0.0f);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lut->inv_w = inv_w;
+        lut->ok = (uint32_t)sok;
+        lut->pad0 = lut->pad1 = 0;
+    }
 }
 
 // ---- K15 ------------------------------------------------------------------------------
@@ -478,8 +527,12 @@ void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const Leve
                       int batch, int rows_per_wave) {
     const int strips = (l.S + kStripCols - 1) / kStripCols;
     const int segs = (l.S + rows_per_wave - 1) / rows_per_wave;
-    hipLaunchKernelGGL(k_sdev_hist<4>, dim3(strips, (segs + kWavesPerBlock - 1) / kWavesPerBlock, batch), dim3(kBlockThreads), 0, st, band,
-                       sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
+    static const int dbg = getenv("MUSICA_DEBUG_SDEV") ? atoi(getenv("MUSICA_DEBUG_SDEV")) : 0;  // timing experiments only
+    const dim3 grid(strips, (segs + kWavesPerBlock - 1) / kWavesPerBlock, batch);
+    if (dbg == 1) hipLaunchKernelGGL((k_sdev_hist<4, false>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
+    else if (dbg == 2) hipLaunchKernelGGL((k_sdev_hist<1, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
+    else if (dbg == 3) hipLaunchKernelGGL((k_sdev_hist<2, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
+    else hipLaunchKernelGGL((k_sdev_hist<4, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
 }
 
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch) {
@@ -488,8 +541,8 @@ void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& 
 }
 
 void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves,
-                         const musica_contrast_params* cparams, int levels, int batch) {
-    hipLaunchKernelGGL(k_noise_curves, dim3(levels, batch), dim3(256), 0, st, hist, hist_stride, maxpts, curves, cparams, levels);
+                         const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts) {
+    hipLaunchKernelGGL(k_noise_curves, dim3(levels, batch), dim3(256), 0, st, hist, hist_stride, maxpts, curves, cparams, levels, luts);
 }
 
 void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& l3, const musica_hist_max_point* maxpts, int levels,

@@ -431,6 +431,12 @@ __global__ void k_lowpass_generic(const float* __restrict__ coarse, float* __res
 // K14 + K16 + K7 + K8 + K17: recon = lowpass(prev) + band * gain(sdev) [* nr(cnr)]
 // ======================================================================================
 
+// linearFunction() of noise_reduction.comp:24-31 with its slope m = (p2.y - p1.y) / (p2.x - p1.x) precomputed.
+__device__ __forceinline__ float nr_factor_m(float c, float lowCnr, float lowFactor, float highCnr, float highFactor, float m) {
+    if (c < lowCnr) return lowFactor;
+    else if (c > highCnr) return highFactor;
+    return m * c + lowFactor;
+}
 // linearFunction() of noise_reduction.comp:24-31 — m * x, not m * (x - p1.x).
 __device__ __forceinline__ float nr_factor(float c, float lowCnr, float lowFactor, float highCnr, float highFactor) {
     if (c < lowCnr) return lowFactor;
@@ -450,14 +456,55 @@ __device__ __forceinline__ float gain_of(float s, float high, const CurveLds& t)
     return curve_eval(t, s);
 }
 
+// The streaming kernel's form of getY() for the 33-point contrast polyline (DevCurveLut):
+// j = #{x[i] < s} from one 16-byte LDS bucket read + two compares for s below 1.75 p, from ten
+// compares against wave-uniform (scalar-register) abscissae above it; x[j-1], y[j-1], m[j-1] then come
+// from LDS. Exactly curve_eval()'s result; degenerate curves take curve_eval()'s literal scan.
+constexpr int kContrastPts = 33;  // 3 x generateCurve(i <= 10), contrast_curve_generate.comp:72-86
+constexpr int kTailPts = kContrastPts - kLutTailFirst;
+struct LutLds {
+    float4 bucket[kLutBuckets];
+    float inv_w;
+    uint32_t ok;
+};
+__device__ __noinline__ float curve_eval_slow(const CurveLds* t, float s) { return curve_eval(*t, s); }
+__device__ __forceinline__ float curve_eval_lut(const float (&xt)[kTailPts], const CurveLds& t, const LutLds& lut, bool lut_ok, float s) {
+    if (!lut_ok) return curve_eval_slow(&t, s);  // wave-uniform
+    if (!(s >= 0.0f)) return 0.0f;               // negative or NaN: no interval of getY() matches
+    const float kf = s * lut.inv_w;
+    int j;
+    if (kf < (float)kLutBuckets) {
+        const float4 e = lut.bucket[(int)kf];
+        j = (int)e.x + (e.y < s ? 1 : 0) + (e.z < s ? 1 : 0);
+    } else {
+        j = kLutTailFirst;
+#pragma unroll
+        for (int i = 0; i < kTailPts; i++) j += (xt[i] < s) ? 1 : 0;
+    }
+    if (j == 0) return (t.x[0] == s) ? t.y[0] : 0.0f;
+    if (j >= kContrastPts) return 0.0f;
+    return t.m[j - 1] * (s - t.x[j - 1]) + t.y[j - 1];
+}
+
 template <int GAIN, bool NR, int T>
 __global__ __launch_bounds__(kBlockThreads) void k_expand_fast(ExpandArgs a) {
     __shared__ CurveLds tab;
+    __shared__ LutLds lut;
     const int img = blockIdx.z;
+    float xt[kTailPts];
     if (GAIN == GAIN_CURVE) {
-        curve_to_lds(tab, a.curves + (size_t)img * a.curve_stride);
+        const DevCurve* cv = a.curves + (size_t)img * a.curve_stride;
+        const DevCurveLut* lv = a.luts + (size_t)img * MUSICA_COARSER_LEVELS_START;
+        curve_to_lds(tab, cv);
+        for (int i = threadIdx.x; i < kLutBuckets; i += blockDim.x) lut.bucket[i] = lv->bucket[i];
+        if (threadIdx.x == 0) { lut.inv_w = lv->inv_w; lut.ok = lv->ok; }
+#pragma unroll
+        for (int i = 0; i < kTailPts; i++) xt[i] = cv->x[kLutTailFirst + i];  // uniform address -> scalar loads
         __syncthreads();
     }
+    const bool lut_ok = GAIN == GAIN_CURVE && lut.ok != 0;
+    // slope of noise_reduction.comp:28, the same value for every texel
+    const float nr_m = (a.highFactor - a.lowFactor) / (a.highCnr - a.lowCnr);
     const int lane = threadIdx.x & 63;
     const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
     const int k0 = seg * a.rows_per_wave;
@@ -500,25 +547,26 @@ __global__ __launch_bounds__(kBlockThreads) void k_expand_fast(ExpandArgs a) {
                 if (NR) {
                     const size_t re = (size_t)((2 * kk) / a.cnrScale) * a.cnrPitch, ro = (size_t)((2 * kk + 1) / a.cnrScale) * a.cnrPitch;
                     if (a.cnrScale == 4 || a.cnrScale == 8) {  // columns c..c+3 and c+4..c+7 each sit inside one cnr texel (c % 8 == 0)
-                        const float e0 = nr_factor(cnr[re + cxs[0]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
-                        const float e1 = nr_factor(cnr[re + cxs[1]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
-                        const float o0 = nr_factor(cnr[ro + cxs[0]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
-                        const float o1 = nr_factor(cnr[ro + cxs[1]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
+                        const float e0 = nr_factor_m(cnr[re + cxs[0]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
+                        const float e1 = nr_factor_m(cnr[re + cxs[1]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
+                        const float o0 = nr_factor_m(cnr[ro + cxs[0]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
+                        const float o1 = nr_factor_m(cnr[ro + cxs[1]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
 #pragma unroll
                         for (int j = 0; j < 8; j++) { fe[j] = j < 4 ? e0 : e1; fo[j] = j < 4 ? o0 : o1; }
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
                             const int cx = g.active ? (g.c + j) / a.cnrScale : 0;                 // noise_reduction.comp:39-45
-                            fe[j] = nr_factor(cnr[re + cx] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
-                            fo[j] = nr_factor(cnr[ro + cx] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor);
+                            fe[j] = nr_factor_m(cnr[re + cx] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
+                            fo[j] = nr_factor_m(cnr[ro + cx] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
                         }
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    float pe = be[t][j] * gain_of<GAIN>(GAIN != GAIN_CONST ? se[t][j] : 0.0f, a.high, tab);  // contrast_curve_apply.comp:61
-                    float po = bo[t][j] * gain_of<GAIN>(GAIN != GAIN_CONST ? so[t][j] : 0.0f, a.high, tab);
+                    // contrast_curve_apply.comp:61
+                    float pe = be[t][j] * (GAIN == GAIN_CURVE ? curve_eval_lut(xt, tab, lut, lut_ok, se[t][j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? se[t][j] : 0.0f, a.high, tab));
+                    float po = bo[t][j] * (GAIN == GAIN_CURVE ? curve_eval_lut(xt, tab, lut, lut_ok, so[t][j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? so[t][j] : 0.0f, a.high, tab));
                     if (NR) {
                         pe = pe * fe[j];   // noise_reduction.comp:57
                         po = po * fo[j];

@@ -22,6 +22,7 @@ struct ExpandArgs {
     const float* cnr;    // noise reduction (levels 0, 1)
     float* recon;
     const DevCurve* curves;  // curve of this level for image 0 (GAIN_CURVE)
+    const DevCurveLut* luts; // its bucket table (GAIN_CURVE), stride MUSICA_COARSER_LEVELS_START per image
     int S, pitch; size_t plane;
     int Sc, cpitch; size_t cplane;
     int cnrS, cnrPitch; size_t cnrPlane;
@@ -56,7 +57,7 @@ void launch_normalize(hipStream_t st, const uint16_t* px, float* out, const Leve
 void launch_sqrt(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, int batch);
 void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch, int rows_per_wave);
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch);
-void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves, const musica_contrast_params* cparams, int levels, int batch);
+void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves, const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts);
 void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& l3, const musica_hist_max_point* maxpts, int levels, int batch);
 void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact,
                   const musica_hist_max_point* noise_max, int levels, const musica_hist_max_point* grad_max, const DevCurve* gcurve,

@@ -64,6 +64,7 @@ struct musica_ctx {
     uint32_t* d_noise_hist;
     musica_hist_max_point* d_noise_max;
     DevCurve* d_curves;
+    DevCurveLut* d_luts;
     musica_contrast_params* d_cparams;
     float* d_cnr;
     uint32_t* d_grad_hist;
@@ -208,7 +209,7 @@ musica_ctx* musica_create(const musica_params* params) {
     c->reduce_rows = env_int("MUSICA_REDUCE_ROWS", 16);
     c->reduce_trip = env_int("MUSICA_REDUCE_TRIP", 1);
     c->band_trip = env_int("MUSICA_BAND_TRIP", 2);
-    c->expand_trip = env_int("MUSICA_EXPAND_TRIP", 2);
+    c->expand_trip = env_int("MUSICA_EXPAND_TRIP", 1);
     c->min_waves = env_int("MUSICA_MIN_WAVES", 4096);
     c->band_rows = env_int("MUSICA_BAND_ROWS", 8);
     c->expand_rows = env_int("MUSICA_EXPAND_ROWS", 8);
@@ -221,7 +222,7 @@ musica_ctx* musica_create(const musica_params* params) {
     const size_t B = (size_t)c->B;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && dalloc(c, &c->d_input, B * N * N);
-    ok = ok && dalloc(c, &c->d_minmax, B * 2);
+    ok = ok && dalloc(c, &c->d_minmax, B * kMinMaxStride);
     ok = ok && dalloc(c, &c->d_norm, B * c->lv[0].plane);
     for (int i = 0; i < c->L && ok; i++) {
         ok = ok && dalloc(c, &c->d_down[i], B * c->lv[i + 1].plane);
@@ -232,6 +233,7 @@ musica_ctx* musica_create(const musica_params* params) {
     ok = ok && dalloc(c, &c->d_noise_hist, B * 4 * MUSICA_NOISE_BINS);
     ok = ok && dalloc(c, &c->d_noise_max, B * L);
     ok = ok && dalloc(c, &c->d_curves, B * L);
+    ok = ok && dalloc(c, &c->d_luts, B * MUSICA_COARSER_LEVELS_START);
     ok = ok && dalloc(c, &c->d_cparams, (size_t)L);
     ok = ok && dalloc(c, &c->d_cnr, B * c->lv[MUSICA_CNR_LEVEL].plane);
     ok = ok && dalloc(c, &c->d_grad_hist, B * MUSICA_GRAD_BINS);
@@ -331,7 +333,7 @@ static void enqueue_analysis(musica_ctx* c) {
     }
     {
         Span sp(c, MUSICA_KERNEL_CURVES);
-        launch_noise_curves(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B);
+        launch_noise_curves(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts);
     }
     {
         Span sp(c, MUSICA_KERNEL_CNR);
@@ -350,6 +352,7 @@ static ExpandArgs expand_args(musica_ctx* c, int lvl, float* dst) {
     a.cnr = c->d_cnr;
     a.recon = dst;
     a.curves = c->d_curves + lvl;
+    a.luts = c->d_luts + (lvl < MUSICA_COARSER_LEVELS_START ? lvl : 0);
     a.curve_stride = (size_t)c->L;
     a.S = lf.S; a.pitch = lf.pitch; a.plane = lf.plane;
     a.Sc = lc.S; a.cpitch = lc.pitch; a.cplane = lc.plane;
@@ -659,7 +662,8 @@ int musica_get_nr_params(musica_ctx* c, uint32_t level, musica_nr_params* dst) {
 int musica_get_minmax(musica_ctx* c, uint32_t idx, float* min_sqrt, float* max_sqrt) {
     CHECK_CTX(c); CHECK_IMG(c, idx);
     uint32_t mm[2];
-    if (!download_small(c, c->d_minmax + 2 * (size_t)idx, mm, 2)) return 0;
+    if (!download_small(c, c->d_minmax + kMinMaxStride * (size_t)idx, &mm[0], 1)) return 0;
+    if (!download_small(c, c->d_minmax + kMinMaxStride * (size_t)idx + kMaxWord, &mm[1], 1)) return 0;
     // same scalars the normalize kernel derives (kernels_analysis.hip chain_scalars)
     const float mx = sqrtf((float)mm[1]), mn = sqrtf((float)mm[0]);
     *max_sqrt = (float)(uint32_t)mx;

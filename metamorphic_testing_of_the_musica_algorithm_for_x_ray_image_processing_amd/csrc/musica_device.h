@@ -30,6 +30,8 @@ constexpr int kBlockThreads = 64 * kWavesPerBlock;
 constexpr float kMaxNoiseValue = 0.1f;          // noise_hist.comp:7
 constexpr float kMaxCnrValue = 256.0f;          // img_cnr.comp:6
 constexpr int kHistArea = 16;                   // noise_hist.comp:5
+constexpr int kMinMaxStride = 32;                // uint32 words per image in the min/max scratch (128 B)
+constexpr int kMaxWord = 16;                     // the max lives one 64-byte line after the min
 constexpr int kCurveCap = 64;                   // >= 33 (contrast) and 22 (gradation) points + 1 guard
 
 // A polyline (T3 / T5 of the reference) in structure-of-arrays form plus the per-segment
@@ -44,6 +46,23 @@ struct DevCurve {
     uint32_t monotone;
     float t0, ta, t1;       // gradation window (unused for contrast curves)
     uint32_t pad;
+};
+
+// Exact accelerator for getY() on a 33-point contrast curve (levels 0..2). Texels with
+// s * inv_w < kLutBuckets fall into a uniform bucket that stores how many curve abscissae lie in
+// lower buckets (jlo) and the at most two abscissae inside it (xa <= xb, +inf when absent):
+//   #{x[i] < s} = jlo + (xa < s) + (xb < s).
+// Bucket membership is decided by the same float expression (int)(x * inv_w) when the table is built
+// and when it is read, and that expression is monotone in x, so the count is exact whatever the
+// rounding. Larger s only has the 10 abscissae of the last Bezier span left to compare with.
+// ok == 0 (degenerate curve, e.g. maxBin == 0) sends the level down the literal scan instead.
+constexpr int kLutBuckets = 256;
+constexpr int kLutTailFirst = 23;   // abscissae 0..22 are <= 1.4 p and always inside the table's range
+struct DevCurveLut {
+    float inv_w;
+    uint32_t ok;
+    uint32_t pad0, pad1;
+    float4 bucket[kLutBuckets];     // {jlo (as float), xa, xb, unused}
 };
 
 struct LevelDesc {
