@@ -153,6 +153,82 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_fast(const float* __re
     }
 }
 
+// Software-pipelined form: one output row per trip, and the input rows of the next D trips are
+// already requested while trip k is computed, so a wavefront always has 2*D rows (4*D KiB) of loads in
+// flight behind its arithmetic (2*D more row registers than k_reduce_fast<1>).
+template <int D>
+__global__ __launch_bounds__(kBlockThreads) void k_reduce_fast_pf(const float* __restrict__ in, float* __restrict__ out,
+                                                                  int S, int pitch, size_t in_plane, int So, int opitch,
+                                                                  size_t out_plane, int rows_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int yo0 = seg * rows_per_wave;
+    if (yo0 >= So) return;  // wave-uniform
+    const int yo1 = min(yo0 + rows_per_wave, So);
+    const Buf ib = make_buf(in + (size_t)blockIdx.z * in_plane, in_plane * 4);
+    const Buf ob = make_buf(out + (size_t)blockIdx.z * out_plane, out_plane * 4);
+    const LaneCfg g = make_cfg(blockIdx.x, lane, S);
+    const int hi = S - 1;
+    const uint32_t rb = (uint32_t)pitch * 4u, orb = (uint32_t)opitch * 4u;
+    RowR w[5 + 2 * D];  // rows 2yo-2 .. 2yo+2 of the current trip, then the row pairs of the next D trips
+    load_row(w[0], ib, (uint32_t)mirror_idx(2 * yo0 - 2, hi) * rb, g);
+    load_row(w[1], ib, (uint32_t)mirror_idx(2 * yo0 - 1, hi) * rb, g);
+    load_row(w[2], ib, (uint32_t)(2 * yo0) * rb, g);
+#pragma unroll
+    for (int d = 0; d < D; d++) {  // trips yo0 .. yo0+D-1 (clamped: rows past the segment are requested, never consumed)
+        const int ya = min(yo0 + d, yo1 - 1);
+        load_row(w[3 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + 1, hi) * rb, g);
+        load_row(w[4 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + 2, hi) * rb, g);
+    }
+    for (int yo = yo0; yo < yo1; yo++) {
+        const int yn = min(yo + D, yo1 - 1);
+        load_row(w[3 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + 1, hi) * rb, g);
+        load_row(w[4 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + 2, hi) * rb, g);
+        reduce_row(w[0], w[1], w[2], w[3], w[4], g, ob, (uint32_t)yo * orb);
+#pragma unroll
+        for (int i = 0; i < 3 + 2 * D; i++) w[i] = w[i + 2];
+    }
+}
+
+// Rotating-register form of the pipelined kernel: the 5-row window plus the row pair in flight
+// occupy 7 register slots and the window advances by 2 slots per output row, so after 7 rows the
+// slot assignment repeats. The loop body is unrolled over that period with compile-time slot
+// indices: no register-to-register copies at all (k_reduce_fast_pf spends 77 v_mov per row on them).
+__global__ __launch_bounds__(kBlockThreads) void k_reduce_fast_rot(const float* __restrict__ in, float* __restrict__ out,
+                                                                   int S, int pitch, size_t in_plane, int So, int opitch,
+                                                                   size_t out_plane, int rows_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int yo0 = seg * rows_per_wave;
+    if (yo0 >= So) return;  // wave-uniform
+    const int yo1 = min(yo0 + rows_per_wave, So);
+    const Buf ib = make_buf(in + (size_t)blockIdx.z * in_plane, in_plane * 4);
+    const Buf ob = make_buf(out + (size_t)blockIdx.z * out_plane, out_plane * 4);
+    const LaneCfg g = make_cfg(blockIdx.x, lane, S);
+    const int hi = S - 1;
+    const uint32_t rb = (uint32_t)pitch * 4u, orb = (uint32_t)opitch * 4u;
+    RowR w[7];
+    load_row(w[0], ib, (uint32_t)mirror_idx(2 * yo0 - 2, hi) * rb, g);
+    load_row(w[1], ib, (uint32_t)mirror_idx(2 * yo0 - 1, hi) * rb, g);
+    load_row(w[2], ib, (uint32_t)(2 * yo0) * rb, g);
+    load_row(w[3], ib, (uint32_t)mirror_idx(2 * yo0 + 1, hi) * rb, g);
+    load_row(w[4], ib, (uint32_t)mirror_idx(2 * yo0 + 2, hi) * rb, g);
+    for (int yo = yo0; yo < yo1; yo += 7) {
+#pragma unroll
+        for (int ph = 0; ph < 7; ph++) {
+            if (yo + ph < yo1) {  // wave-uniform
+                constexpr int kSlots = 7;
+                const int base = (2 * ph) % kSlots;
+                const int yn = min(yo + ph + 1, yo1 - 1);  // the last row re-requests its own input (never consumed)
+                load_row(w[(base + 5) % kSlots], ib, (uint32_t)mirror_idx(2 * yn + 1, hi) * rb, g);
+                load_row(w[(base + 6) % kSlots], ib, (uint32_t)mirror_idx(2 * yn + 2, hi) * rb, g);
+                reduce_row(w[base], w[(base + 1) % kSlots], w[(base + 2) % kSlots], w[(base + 3) % kSlots], w[(base + 4) % kSlots], g, ob,
+                           (uint32_t)(yo + ph) * orb);
+            }
+        }
+    }
+}
+
 // LDS-tiled form of the same kernel (S % 8 == 0): a 256-thread workgroup produces a 64 x 16 output
 // tile from a (2*16+3) x (2*64+8) input tile staged in LDS. Every thread issues its 4-5 16-byte
 // global loads back to back, so a CU with 5 resident workgroups keeps ~95 KiB outstanding and
@@ -657,7 +733,13 @@ void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* 
                            li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane);
     } else if (fast_ok(li.S) && !force_generic) {
         const dim3 grid = stream_grid(li.S, lo.S, rows_per_wave, batch);
-        if (rows_per_trip >= 4)
+        if (rows_per_trip <= -3)
+            hipLaunchKernelGGL(k_reduce_fast_rot, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
+        else if (rows_per_trip <= -2)
+            hipLaunchKernelGGL(k_reduce_fast_pf<2>, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
+        else if (rows_per_trip < 0)
+            hipLaunchKernelGGL(k_reduce_fast_pf<1>, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
+        else if (rows_per_trip >= 4)
             hipLaunchKernelGGL(k_reduce_fast<4>, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
         else if (rows_per_trip >= 2)
             hipLaunchKernelGGL(k_reduce_fast<2>, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);

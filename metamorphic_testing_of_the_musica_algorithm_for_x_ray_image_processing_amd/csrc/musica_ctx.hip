@@ -207,10 +207,10 @@ musica_ctx* musica_create(const musica_params* params) {
     for (int i = 0; i < c->L; i++) c->h_cparams[i] = host_contrast_params((uint32_t)i, L);
     for (int i = 0; i < 3; i++) c->h_nr[i] = host_nr_params((uint32_t)i);
     c->reduce_rows = env_int("MUSICA_REDUCE_ROWS", 16);
-    c->reduce_trip = env_int("MUSICA_REDUCE_TRIP", 1);
+    c->reduce_trip = env_int("MUSICA_REDUCE_TRIP", -1);
     c->band_trip = env_int("MUSICA_BAND_TRIP", 2);
     c->expand_trip = env_int("MUSICA_EXPAND_TRIP", 1);
-    c->min_waves = env_int("MUSICA_MIN_WAVES", 4096);
+    c->min_waves = env_int("MUSICA_MIN_WAVES", 2048);
     c->band_rows = env_int("MUSICA_BAND_ROWS", 8);
     c->expand_rows = env_int("MUSICA_EXPAND_ROWS", 8);
     c->sdev_rows = env_int("MUSICA_SDEV_ROWS", 32) & ~15;
