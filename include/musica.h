@@ -99,6 +99,7 @@ typedef struct musica_stats {
 #define MUSICA_FLAG_CLAHE      0x1u /* CLAHE gradation (reference: #ifdef ENABLE_CLAHE, vk_processing.h:13) */
 #define MUSICA_FLAG_NO_GRAPH   0x2u /* launch kernels eagerly instead of replaying a captured hipGraph */
 #define MUSICA_FLAG_GENERIC_KERNELS 0x4u /* test hook: use the one-thread-per-texel kernels at every level */
+#define MUSICA_FLAG_NO_AUTOTUNE 0x8u /* skip the init-time launch-geometry autotune (rows per wavefront stay heuristic) */
 
 /* Construction parameters: the reference hard-wires these as literals
  * (imageSize = 3072 in test/standalone/main.cpp:31; L = ceil(log2 N) in

@@ -156,7 +156,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_fast(const float* __re
 // Software-pipelined form: one output row per trip, and the input rows of the next D trips are
 // already requested while trip k is computed, so a wavefront always has 2*D rows (4*D KiB) of loads in
 // flight behind its arithmetic (2*D more row registers than k_reduce_fast<1>).
-template <int D>
+// TAG only separates the launch sites in profiler output (one symbol per site, so rocprofv3's
+// per-kernel averages are not a mix of pyramid levels): 0 = level 0 of the pipeline, 1 = levels >= 1,
+// 2 = stand-alone musica_k_reduce, 3 = init-time autotune.
+template <int D, int TAG>
 __global__ __launch_bounds__(kBlockThreads) void k_reduce_fast_pf(const float* __restrict__ in, float* __restrict__ out,
                                                                   int S, int pitch, size_t in_plane, int So, int opitch,
                                                                   size_t out_plane, int rows_per_wave) {
@@ -727,7 +730,7 @@ static inline bool fast_ok(int S) { return S >= 8 && (S % 8) == 0; }
 
 // rows_per_trip: 0 selects the LDS-tiled kernel, 1 / 2 / 4 the streaming kernel with that many rows per trip
 void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch,
-                   int rows_per_wave, bool force_generic, int rows_per_trip) {
+                   int rows_per_wave, bool force_generic, int rows_per_trip, int tag) {
     if (fast_ok(li.S) && !force_generic && rows_per_trip == 0) {
         hipLaunchKernelGGL(k_reduce_tiled, dim3((lo.S + kTileW - 1) / kTileW, (lo.S + kTileH - 1) / kTileH, batch), dim3(256), 0, st, in, out,
                            li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane);
@@ -736,9 +739,12 @@ void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* 
         if (rows_per_trip <= -3)
             hipLaunchKernelGGL(k_reduce_fast_rot, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
         else if (rows_per_trip <= -2)
-            hipLaunchKernelGGL(k_reduce_fast_pf<2>, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
+            hipLaunchKernelGGL((k_reduce_fast_pf<2, 0>), grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
         else if (rows_per_trip < 0)
-            hipLaunchKernelGGL(k_reduce_fast_pf<1>, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
+        {
+            auto* kern = tag == 0 ? k_reduce_fast_pf<1, 0> : tag == 1 ? k_reduce_fast_pf<1, 1> : tag == 2 ? k_reduce_fast_pf<1, 2> : k_reduce_fast_pf<1, 3>;
+            hipLaunchKernelGGL(kern, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
+        }
         else if (rows_per_trip >= 4)
             hipLaunchKernelGGL(k_reduce_fast<4>, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
         else if (rows_per_trip >= 2)

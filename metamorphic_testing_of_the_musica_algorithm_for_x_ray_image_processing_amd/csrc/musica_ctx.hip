@@ -48,6 +48,7 @@ struct musica_ctx {
     musica_params p;
     int N, L, B;
     bool generic;
+    bool tuning;  // inside autotune(): launches are tagged so profilers keep them apart
     LevelDesc lv[MUSICA_MAX_LEVELS + 1];
     int min_chain_exact;
     int hist_cov;  // (N / 512) * 512
@@ -79,6 +80,8 @@ struct musica_ctx {
     // host parameters (src/vk_processing.cpp:259-297, 321-325)
     musica_contrast_params h_cparams[MUSICA_MAX_LEVELS];
     musica_nr_params h_nr[3];
+    // rows each wavefront marches per launch, per level (heuristic, then autotuned at create)
+    int rows_reduce[MUSICA_MAX_LEVELS], rows_band[MUSICA_MAX_LEVELS], rows_expand[MUSICA_MAX_LEVELS], rows_sdev[4];
     // tunables
     int reduce_rows, band_rows, expand_rows, sdev_rows, grad_groups, reduce_trip, band_trip, expand_trip, min_waves;
     // profiling
@@ -132,6 +135,8 @@ static musica_nr_params host_nr_params(uint32_t i) {
     q.lowFactor = nrMinLowFactor + (1.0f - nrMinLowFactor) * ((float)i / (float)MUSICA_CNR_LEVEL);
     return q;
 }
+
+static void autotune(musica_ctx* c);
 
 static uint32_t cnr_scale(int S, int cnrS) { return (uint32_t)ceilf((float)S / (float)cnrS); }  // noise_reduction.comp:38
 
@@ -192,6 +197,7 @@ musica_ctx* musica_create(const musica_params* params) {
     c->N = (int)N; c->L = (int)L; c->B = params->batch ? (int)params->batch : 1;
     c->p.levels = L; c->p.batch = (uint32_t)c->B;
     c->generic = (params->flags & MUSICA_FLAG_GENERIC_KERNELS) != 0;
+    c->tuning = false;
     c->stream = nullptr; c->profiling = 0; c->spans_used = 0; c->cur_input = nullptr;
     memset(c->prof_total_us, 0, sizeof(c->prof_total_us));
     memset(c->prof_count, 0, sizeof(c->prof_count));
@@ -256,6 +262,13 @@ musica_ctx* musica_create(const musica_params* params) {
         return nullptr;
     }
     c->cur_input = c->d_input;
+    for (int i = 0; i < c->L; i++) {
+        c->rows_reduce[i] = pick_rows(c->reduce_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
+        c->rows_band[i] = pick_rows(c->band_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
+        c->rows_expand[i] = pick_rows(c->expand_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
+        if (i <= MUSICA_CNR_LEVEL) c->rows_sdev[i] = pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, c->B);
+    }
+    if (!(params->flags & MUSICA_FLAG_NO_AUTOTUNE) && env_int("MUSICA_AUTOTUNE", 1) && !c->generic) autotune(c);
     return c;
 }
 
@@ -308,19 +321,22 @@ static void enqueue_norm(musica_ctx* c) {
     { Span sp(c, MUSICA_KERNEL_NORMALIZE); launch_normalize(c->stream, c->cur_input, c->d_norm, c->lv[0], c->d_minmax, c->min_chain_exact, c->B); }
 }
 
+static void run_reduce_level(musica_ctx* c, int i, int rows) {
+    launch_reduce(c->stream, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, rows, c->generic, c->reduce_trip, c->tuning ? 3 : (i == 0 ? 0 : 1));
+}
+static void run_band_level(musica_ctx* c, int i, int rows) {
+    launch_band(c->stream, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, rows, c->generic, c->band_trip);
+}
+static void run_sdev_level(musica_ctx* c, int i, int rows) {
+    launch_sdev_hist(c->stream, c->d_band[i], c->d_sdev[i], c->lv[i], c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS,
+                     (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov, c->B, rows);
+}
+
 // stage "red" (src/vk_processing.cpp:2233-2273)
 static void enqueue_reduce(musica_ctx* c) {
     for (int i = 0; i < c->L; i++) {
-        const LevelDesc& lf = c->lv[i];
-        const LevelDesc& lc = c->lv[i + 1];
-        {
-            Span sp(c, i == 0 ? MUSICA_KERNEL_REDUCE_L0 : MUSICA_KERNEL_REDUCE_REST);
-            launch_reduce(c->stream, level_input(c, i), lf, c->d_down[i], lc, c->B, pick_rows(c->reduce_rows, 1, lf.S, lc.S, c->B), c->generic, c->reduce_trip);
-        }
-        {
-            Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST);
-            launch_band(c->stream, level_input(c, i), c->d_down[i], c->d_band[i], lf, lc, c->B, pick_rows(c->band_rows, 1, lf.S, lc.S, c->B), c->generic, c->band_trip);
-        }
+        { Span sp(c, i == 0 ? MUSICA_KERNEL_REDUCE_L0 : MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
+        { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
     }
 }
 
@@ -328,8 +344,7 @@ static void enqueue_reduce(musica_ctx* c) {
 static void enqueue_analysis(musica_ctx* c) {
     for (int i = 0; i <= MUSICA_CNR_LEVEL; i++) {  // i < coarserLevelsStart || i <= cnrLevel, :2285
         Span sp(c, MUSICA_KERNEL_SDEV_HIST);
-        launch_sdev_hist(c->stream, c->d_band[i], c->d_sdev[i], c->lv[i], c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS,
-                         (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov, c->B, pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, c->B));
+        run_sdev_level(c, i, c->rows_sdev[i]);
     }
     {
         Span sp(c, MUSICA_KERNEL_CURVES);
@@ -361,18 +376,23 @@ static ExpandArgs expand_args(musica_ctx* c, int lvl, float* dst) {
     a.high = c->h_cparams[lvl].highContrastFactor;
     const musica_nr_params& q = c->h_nr[lvl < 3 ? lvl : 0];
     a.lowCnr = q.lowCnr; a.lowFactor = q.lowFactor; a.highCnr = q.highCnr; a.highFactor = q.highFactor;
-    a.rows_per_wave = pick_rows(c->expand_rows, 1, lf.S, lc.S, c->B);
+    a.rows_per_wave = c->rows_expand[lvl];
     return a;
 }
 static int gain_mode(int lvl) { return lvl > MUSICA_CNR_LEVEL ? GAIN_CONST : (lvl == MUSICA_CNR_LEVEL ? GAIN_RANGE : GAIN_CURVE); }
 static bool uses_nr(int lvl) { return lvl < MUSICA_CNR_LEVEL - 1; }  // currentLevel < cnrLevel - 1, src/vk_processing.cpp:1009-1016
 
+static void run_expand_level(musica_ctx* c, int lvl, int rows) {
+    ExpandArgs a = expand_args(c, lvl, c->d_recon[lvl]);
+    a.rows_per_wave = rows;
+    launch_expand(c->stream, a, gain_mode(lvl), uses_nr(lvl), c->B, c->generic, c->expand_trip);
+}
+
 // stages "aply" + "exp" (src/vk_processing.cpp:2361-2431)
 static void enqueue_expand(musica_ctx* c) {
     for (int lvl = c->L - 1; lvl >= 0; lvl--) {
         Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
-        const ExpandArgs a = expand_args(c, lvl, c->d_recon[lvl]);
-        launch_expand(c->stream, a, gain_mode(lvl), uses_nr(lvl), c->B, c->generic, c->expand_trip);
+        run_expand_level(c, lvl, c->rows_expand[lvl]);
     }
 }
 
@@ -408,6 +428,74 @@ static int enqueue_all(musica_ctx* c) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e));
     return 1;
+}
+
+// ---- init-time autotune ------------------------------------------------------------------
+// How many rows a wavefront marches decides both the number of wavefronts and the halo re-reads;
+// the best value depends on level size, batch and how the workgroups spread over the 8 XCDs, and
+// no closed form predicted it on MI355X ("Launch geometry"). So musica_create runs the
+// pipeline once on a synthetic input and then times each streaming kernel of every large level for
+// a handful of candidates with HIP events, keeping the fastest. Results are independent of the
+// choice (the kernels are bit-identical for every row count); only the speed changes.
+static float time_launches(musica_ctx* c, hipEvent_t a, hipEvent_t b, int reps, void (*fn)(musica_ctx*, int, int), int level, int rows) {
+    fn(c, level, rows);  // warm
+    float best = 1e30f;
+    for (int r = 0; r < reps; r++) {
+        hipEventRecord(a, c->stream);
+        fn(c, level, rows);
+        fn(c, level, rows);
+        hipEventRecord(b, c->stream);
+        hipEventSynchronize(b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, a, b) == hipSuccess && ms < best) best = ms;
+    }
+    return best;
+}
+
+static void autotune(musica_ctx* c) {
+    const size_t n = (size_t)c->B * c->N * c->N;
+    std::vector<uint16_t> px(n);
+    uint32_t h = 12345u;
+    for (int b = 0; b < c->B; b++)
+        for (int y = 0; y < c->N; y++)
+            for (int x = 0; x < c->N; x++) {
+                h = h * 1664525u + 1013904223u;
+                const float base = 20000.0f + 12000.0f * sinf(0.011f * x + b) * cosf(0.007f * y) + ((x / 97 + y / 61) & 1) * 6000.0f;
+                const float noise = (float)((h >> 9) & 0xFFFF) / 65536.0f - 0.5f;
+                px[((size_t)b * c->N + y) * c->N + x] = (uint16_t)fminf(65535.0f, fmaxf(1.0f, base + 2.0f * sqrtf(base) * noise));
+            }
+    if (hipMemcpy(c->d_input, px.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) return;
+    c->cur_input = c->d_input;
+    if (!enqueue_all(c)) return;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    c->tuning = true;
+    const int reps = 3;
+    static const int cand_reduce[] = {4, 8, 12, 16, 32};
+    static const int cand_pair[] = {2, 4, 8, 16};   // band / expand count coarse rows (two fine rows each)
+    static const int cand_sdev[] = {16, 32, 64};
+    for (int i = 0; i < c->L; i++) {
+        if (c->lv[i].S < 512 || (c->lv[i].S % 8) != 0) continue;   // small levels are launch-bound: keep the heuristic
+        struct { int* slot; const int* cand; int ncand; void (*fn)(musica_ctx*, int, int); bool use; } jobs[4] = {
+            {&c->rows_reduce[i], cand_reduce, 5, run_reduce_level, true},
+            {&c->rows_band[i], cand_pair, 4, run_band_level, true},
+            {&c->rows_expand[i], cand_pair, 4, run_expand_level, true},
+            {i <= MUSICA_CNR_LEVEL ? &c->rows_sdev[i] : nullptr, cand_sdev, 3, run_sdev_level, i <= MUSICA_CNR_LEVEL},
+        };
+        for (auto& j : jobs) {
+            if (!j.use) continue;
+            float best = time_launches(c, a, b, reps, j.fn, i, *j.slot);
+            for (int k = 0; k < j.ncand; k++) {
+                if (j.cand[k] == *j.slot) continue;
+                const float t = time_launches(c, a, b, reps, j.fn, i, j.cand[k]);
+                if (t < best * 0.97f) { best = t; *j.slot = j.cand[k]; }   // 3 % hysteresis against timer noise
+            }
+        }
+    }
+    c->tuning = false;
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    hipStreamSynchronize(c->stream);
 }
 
 // pitched device plane -> dense host image
@@ -810,7 +898,7 @@ int musica_k_reduce(musica_ctx* c, const float* d_in, uint32_t side, uint32_t in
     CHECK_CTX(c);
     LevelDesc li, lo;
     if (!reduce_descs(side, in_pitch, out_pitch, &li, &lo)) return 0;
-    launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, pick_rows(c->reduce_rows, 1, li.S, lo.S, (int)batch), c->generic, c->reduce_trip);
+    launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, pick_rows(c->reduce_rows, 1, li.S, lo.S, (int)batch), c->generic, c->reduce_trip, 2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e));
     return 1;
@@ -827,7 +915,7 @@ int musica_k_reduce_timed(musica_ctx* c, const float* d_in, uint32_t side, uint3
     HIP_OK(hipEventCreate(&a));
     HIP_OK(hipEventCreate(&b));
     HIP_OK(hipEventRecord(a, c->stream));
-    for (uint32_t i = 0; i < iters; i++) launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, rpw, c->generic, c->reduce_trip);
+    for (uint32_t i = 0; i < iters; i++) launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, rpw, c->generic, c->reduce_trip, 2);
     HIP_OK(hipEventRecord(b, c->stream));
     HIP_OK(hipEventSynchronize(b));
     float ms = 0.f;

@@ -1,0 +1,113 @@
+"""N > 1 path of the batch driver, rehearsed with world_size-2 gloo processes on CPU.
+
+The shard assignment and the statistics all-gather are exactly the code bench.py runs on GPUs; only the
+per-image compute is replaced here by the CPU oracle (test infrastructure), which fills the same
+`musica_stats` struct. Rendezvous on 127.0.0.1 (the container hostname may not resolve).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N, LEVELS, TOTAL = 256, 5, 6
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_row(ob, batch, px, image_id):
+    o = ob.Oracle(N, LEVELS, ob.ORDER_FAST).execute(px)
+    st = o.stats()
+    st.image_id = image_id
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.processing import Stats
+    return batch.stats_to_row(Stats.from_buffer_copy(bytes(st)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd import batch
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.phantom import phantom
+    from oracle import binding as ob
+    ob.set_threads(2)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids = batch.assign_images(TOTAL, world)[rank]
+    rows = np.stack([_oracle_row(ob, batch, phantom(N, 100 + k), k) for k in ids])
+    gathered = batch.gather_rows(rows, world, dist)
+    dist.barrier()
+    if rank == 0:
+        q.put(np.asarray(gathered))
+    dist.destroy_process_group()
+
+
+def test_assign_images():
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd import batch
+    a = batch.assign_images(64, 8)
+    assert [len(x) for x in a] == [8] * 8
+    assert a[3][:3] == [3, 11, 19]
+    assert sorted(sum(batch.assign_images(7, 3), [])) == list(range(7))
+    assert batch.STATS_WORDS == 17
+
+
+def test_stats_row_roundtrip(ob):
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd import batch
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.phantom import phantom
+    row = _oracle_row(ob, batch, phantom(N, 5), 42)
+    s = batch.row_to_stats(row)
+    assert s.image_id == 42 and 0.0 <= s.t0 <= s.ta <= 1.0
+    d = batch.summarize(np.stack([row]))
+    assert d[0]["image_id"] == 42 and len(d[0]["noise_max_bin"]) == 4
+
+
+def test_two_rank_gloo_gather_matches_single_process(ob):
+    import torch.multiprocessing as mp
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd import batch
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.phantom import phantom
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert gathered.shape == (TOTAL, batch.STATS_WORDS)
+    got = {int(batch.row_to_stats(r).image_id): r for r in gathered}
+    assert sorted(got) == list(range(TOTAL))
+    for k in range(TOTAL):
+        expect = _oracle_row(ob, batch, phantom(N, 100 + k), k)
+        assert np.array_equal(got[k], expect), "image %d" % k
+    # rank order: the all-gather concatenates rank 0's rows (0, 2, 4) then rank 1's (1, 3, 5)
+    assert [int(batch.row_to_stats(r).image_id) for r in gathered] == [0, 2, 4, 1, 3, 5]
+
+
+@pytest.mark.gpu
+def test_process_shard_on_gpu_matches_oracle(ob):
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd import batch
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd import processing as mp_
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.phantom import phantom
+    ids = [0, 2, 4]
+    imgs = np.stack([phantom(N, 100 + k) for k in ids])
+    proc = mp_.MusicaProcessing()
+    assert proc.init(N, levels=LEVELS, batch=2)
+    rows = batch.process_shard(proc, imgs, ids)
+    for r, k in zip(rows, ids):
+        e = batch.row_to_stats(_oracle_row(ob, batch, phantom(N, 100 + k), k))
+        g = batch.row_to_stats(r)
+        assert g.image_id == k
+        assert list(g.noise_max_bin) == list(e.noise_max_bin) and g.grad_max_bin == e.grad_max_bin
+        assert (g.t0, g.ta, g.t1, g.min_sqrt, g.max_sqrt) == (e.t0, e.ta, e.t1, e.min_sqrt, e.max_sqrt)
+        assert abs(g.mean_cnr - e.mean_cnr) <= 1e-5 * max(1.0, abs(e.mean_cnr))
+    proc.cleanup()
