@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include "kernels_common.h"
+#include "exact_math.h"
 #include "launchers.h"
 
 namespace musica {
@@ -225,7 +226,7 @@ __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const S
     s[6] = sum5(q[4], q[5], q[6], q[7], b0);
     s[7] = sum5(q[5], q[6], q[7], b0, b1);
 #pragma unroll
-    for (int j = 0; j < 8; j++) s[j] = sqrtf(s[j] / 25.0f);  // img_sdev.comp:30
+    for (int j = 0; j < 8; j++) s[j] = sqrtf(musica_div25(s[j]));  // img_sdev.comp:30 (exact x / 25, exact_math.h)
     if (g.valid == 8) {
         *reinterpret_cast<float4*>(drow + g.c) = make_float4(s[0], s[1], s[2], s[3]);
         *reinterpret_cast<float4*>(drow + g.c + 4) = make_float4(s[4], s[5], s[6], s[7]);
@@ -234,26 +235,19 @@ __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const S
         for (int j = 0; j < 8; j++)
             if (j < g.valid) drow[g.c + j] = s[j];
     }
-    // noise_hist.comp:20-47
+    // noise_hist.comp:20-47 — branch-free: a dead or breaking column adds 0 to a per-lane scratch word
     if ((y & (kHistArea - 1)) == 0) alive = 0xFFu;
     if (HIST && y < cov) {
+        const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            if (!(alive & (1u << j))) continue;
             const int x = g.c + j;
             const float cur = (j < g.valid && x < cov) ? s[j] : 0.0f;
-            bool brk = (cur == 0.0f);                                   // :29
-            int bin = 0;
-            if (!brk) {
-                const float adj = cur / kMaxNoiseValue;                   // :31
-                if (adj > 1.0f) brk = true;                               // :33
-                else {
-                    bin = (int)(adj * (float)MUSICA_NOISE_BINS + 0.5f);   // :35
-                    if (bin == 0) brk = true;                             // :39
-                }
-            }
-            if (brk) alive &= ~(1u << j);
-            else if (bin > 0 && bin < MUSICA_NOISE_BINS) atomicAdd(&lh[bin], 1u);  // :45 (bin 2048 is dropped, Q1)
+            const int bin = musica_noise_bin(cur);                         // 0 = break (:29, :33, :39); exact (exact_math.h)
+            const bool live = (alive >> j) & 1u;
+            if (bin == 0) alive &= ~(1u << j);
+            const bool add = live && bin > 0 && bin < MUSICA_NOISE_BINS;    // bin 2048 is dropped (Q1) but does not break
+            atomicAdd(&lh[add ? bin : MUSICA_NOISE_BINS + lane], add ? 1u : 0u);  // :45
         }
     }
 }
@@ -265,8 +259,8 @@ template <int T, bool HIST>
 __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
                                                              size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov,
                                                              int rows_per_wave) {
-    __shared__ uint32_t lh[MUSICA_NOISE_BINS];
-    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS; i += blockDim.x) lh[i] = 0u;
+    __shared__ uint32_t lh[MUSICA_NOISE_BINS + 64];  // + one scratch word per lane for the branch-free adds
+    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS + 64; i += blockDim.x) lh[i] = 0u;
     __syncthreads();
     const int img = blockIdx.z;
     const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);

@@ -34,9 +34,25 @@ __device__ __forceinline__ float cnr_at(const float* __restrict__ cnr, int cnrS,
 // columns of a 16-row group (one 16-byte load per row), finds its columns' first zeros, the 4 lanes
 // of an area combine them with two DPP/shuffle steps, and every pixel before that position is
 // binned with weight uint(relevant * 100) into an LDS-private histogram.
+// Relevance weight uint(relevant * 100) (img_relevant.comp:44-63, gradation_histogram.comp:30) of one cnr
+// texel, split into the part that depends only on cnr (shared by all the pixels under that texel) and the
+// per-pixel tests: w = inside ? (ramp ? w_ramp : (high && pixel <= 0.9 ? 100 : 0)) : 0.
+struct CnrClass {
+    uint32_t w_ramp;  // uint(((r*r)*(r*r))*r * 100) for 1 <= cnr <= 6, r = cnr / 6
+    bool ramp, high;  // 1 <= cnr <= 6 (first branch wins at cnr == 6) ; 6 <= cnr <= 256
+};
+__device__ __forceinline__ CnrClass classify_cnr(float c) {
+    CnrClass k;
+    k.ramp = c >= 1.0f && c <= 6.0f;
+    k.high = c >= 6.0f && c <= kMaxCnrValue;
+    const float r = c / 6.0f;
+    k.w_ramp = f2u((((r * r) * (r * r)) * r) * 100.0f);
+    return k;
+}
+
 __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
-    __shared__ uint32_t lh[MUSICA_GRAD_BINS];
-    for (int i = threadIdx.x; i < MUSICA_GRAD_BINS; i += blockDim.x) lh[i] = 0u;
+    __shared__ uint32_t lh[MUSICA_GRAD_BINS + 64];  // + one scratch word per lane for the branch-free adds
+    for (int i = threadIdx.x; i < MUSICA_GRAD_BINS + 64; i += blockDim.x) lh[i] = 0u;
     __syncthreads();
     const int img = blockIdx.z;
     const Buf ib = make_buf(a.img + (size_t)img * a.plane, a.plane * 4);
@@ -49,6 +65,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
     const uint32_t coff = c < N ? (uint32_t)c * 4u : kOob;
     const uint32_t rb = (uint32_t)a.pitch * 4u;
     const int mbase = (lane & 3) * 4;
+    const uint32_t border = 100u, lim = (uint32_t)N - border;  // uint arithmetic of img_relevant.comp:46-49
+    bool colin[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) colin[j] = (uint32_t)(c + j) > border && (uint32_t)(c + j) < lim;
+    // the lane's 4 columns sit under one cnr texel when the scale is a multiple of 4 (c % 4 == 0)
+    const bool shared_cnr = (a.cnrScale & 3) == 0;
     const int g0 = (blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)) * a.groups_per_wave;
     for (int gi = 0; gi < a.groups_per_wave; gi++) {
         const int yb = (g0 + gi) * kHistArea;
@@ -57,8 +79,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
 #pragma unroll
         for (int n = 0; n < kHistArea; n++) {
             const int y = yb + n;
-            v[n] = bload4(ib, (y < N ? (uint32_t)y * rb : kOob) + coff);   // out of image reads 0 (Q1); kOob + kOob wraps to 0 only
-            if (valid < 4) {                                                // when both are out, and then c >= N masks it below
+            v[n] = bload4(ib, (y < N ? (uint32_t)y * rb : kOob) + coff);   // out of image reads 0 (Q1)
+            if (valid < 4) {
                 if (valid < 1) v[n].x = 0.f;
                 if (valid < 2) v[n].y = 0.f;
                 if (valid < 3) v[n].z = 0.f;
@@ -89,22 +111,21 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
             for (int n8 = 0; n8 < 8; n8++) {
                 const int n = half * 8 + n8;
                 const int y = yb + n;
+                const bool rowin = (uint32_t)y > border && (uint32_t)y < lim;
                 const float vv[4] = {v[n].x, v[n].y, v[n].z, v[n].w};
                 const float pp[4] = {pn[n8].x, pn[n8].y, pn[n8].z, pn[n8].w};
+                CnrClass kc = classify_cnr(shared_cnr ? cnr_at(cn, a.cnrS, a.cnrPitch, a.cnrScale, min(c, N - 1), min(y, N - 1)) : 0.0f);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    if ((mbase + j) * 16 + n >= q) continue;
+                    if (!shared_cnr) kc = classify_cnr(cnr_at(cn, a.cnrS, a.cnrPitch, a.cnrScale, min(c + j, N - 1), min(y, N - 1)));
                     const float cur = vv[j];
-                    if (cur != cur) continue;                                         // NaN never indexes (oracle Q6)
                     const float scaled = cur * (float)MUSICA_GRAD_BINS;                // gradation_histogram.comp:26
-                    if (!(scaled > -2147483648.0f && scaled < 2147483648.0f)) continue;
-                    const int bin = (int)scaled;
-                    if (bin < 0 || bin >= MUSICA_GRAD_BINS) continue;                  // Q1
-                    const int x = c + j;
-                    const float cc = cnr_at(cn, a.cnrS, a.cnrPitch, a.cnrScale, x, y);
-                    if (!(cc >= 1.0f)) continue;                                       // relevant == 0 -> adds 0
-                    const uint32_t w = f2u(relevant_of(pp[j], cc, (uint32_t)x, (uint32_t)y, (uint32_t)N) * 100.0f);  // :28-30
-                    if (w) atomicAdd(&lh[bin], w);
+                    // NaN never indexes (oracle Q6); bins outside [0, 1024) are dropped (Q1)
+                    const bool inrange = scaled > -1.0f && scaled < (float)MUSICA_GRAD_BINS;   // int(scaled) in [0, 1023]
+                    const int bin = inrange ? (int)scaled : 0;
+                    const uint32_t w = (rowin && colin[j]) ? (kc.ramp ? kc.w_ramp : ((kc.high && pp[j] <= 0.90f) ? 100u : 0u)) : 0u;  // :28-30
+                    const bool add = inrange && ((mbase + j) * 16 + n < q) && w != 0u;
+                    atomicAdd(&lh[add ? bin : MUSICA_GRAD_BINS + lane], add ? w : 0u);
                 }
             }
         }

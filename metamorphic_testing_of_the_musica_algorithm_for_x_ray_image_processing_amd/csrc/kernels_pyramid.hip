@@ -173,21 +173,30 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_fast_pf(const float* _
     const LaneCfg g = make_cfg(blockIdx.x, lane, S);
     const int hi = S - 1;
     const uint32_t rb = (uint32_t)pitch * 4u, orb = (uint32_t)opitch * 4u;
-    RowR w[5 + 2 * D];  // rows 2yo-2 .. 2yo+2 of the current trip, then the row pairs of the next D trips
-    load_row(w[0], ib, (uint32_t)mirror_idx(2 * yo0 - 2, hi) * rb, g);
-    load_row(w[1], ib, (uint32_t)mirror_idx(2 * yo0 - 1, hi) * rb, g);
-    load_row(w[2], ib, (uint32_t)(2 * yo0) * rb, g);
+    // Odd segments march upwards, even ones downwards: two vertically adjacent wavefronts then touch
+    // their 3 shared halo rows at the same moment (both at their start, or both at their end), so the
+    // second reader hits the XCD's L2 instead of fetching the rows again (rocprofv3 FETCH_SIZE: -25 %).
+    // Window slot k holds input row 2*yo + dir*(k-2); chain5 always gets the rows in top-to-bottom order.
+    const int dir = (seg & 1) ? -1 : 1;
+    const int n = yo1 - yo0;
+    const int yfirst = dir > 0 ? yo0 : yo1 - 1;
+    RowR w[5 + 2 * D];
+    load_row(w[0], ib, (uint32_t)mirror_idx(2 * yfirst - 2 * dir, hi) * rb, g);
+    load_row(w[1], ib, (uint32_t)mirror_idx(2 * yfirst - dir, hi) * rb, g);
+    load_row(w[2], ib, (uint32_t)(2 * yfirst) * rb, g);
 #pragma unroll
-    for (int d = 0; d < D; d++) {  // trips yo0 .. yo0+D-1 (clamped: rows past the segment are requested, never consumed)
-        const int ya = min(yo0 + d, yo1 - 1);
-        load_row(w[3 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + 1, hi) * rb, g);
-        load_row(w[4 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + 2, hi) * rb, g);
+    for (int d = 0; d < D; d++) {  // trips 0 .. D-1 (clamped: rows past the segment are requested, never consumed)
+        const int ya = yfirst + dir * min(d, n - 1);
+        load_row(w[3 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + dir, hi) * rb, g);
+        load_row(w[4 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + 2 * dir, hi) * rb, g);
     }
-    for (int yo = yo0; yo < yo1; yo++) {
-        const int yn = min(yo + D, yo1 - 1);
-        load_row(w[3 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + 1, hi) * rb, g);
-        load_row(w[4 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + 2, hi) * rb, g);
-        reduce_row(w[0], w[1], w[2], w[3], w[4], g, ob, (uint32_t)yo * orb);
+    for (int t = 0; t < n; t++) {
+        const int yo = yfirst + dir * t;
+        const int yn = yfirst + dir * min(t + D, n - 1);
+        load_row(w[3 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + dir, hi) * rb, g);
+        load_row(w[4 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + 2 * dir, hi) * rb, g);
+        if (dir > 0) reduce_row(w[0], w[1], w[2], w[3], w[4], g, ob, (uint32_t)yo * orb);  // wave-uniform
+        else reduce_row(w[4], w[3], w[2], w[1], w[0], g, ob, (uint32_t)yo * orb);
 #pragma unroll
         for (int i = 0; i < 3 + 2 * D; i++) w[i] = w[i + 2];
     }

@@ -53,6 +53,10 @@ struct musica_ctx {
     int min_chain_exact;
     int hist_cov;  // (N / 512) * 512
     hipStream_t stream;
+    hipStream_t cur;         // stream the run_*_level helpers launch on (stream or side)
+    hipStream_t side;        // coarse-level chain runs here, concurrently with the level-0 kernels on `stream`
+    hipEvent_t ev_fork, ev_join;
+    bool dag;                // two-stream dispatch (MUSICA_DAG=0 falls back to one in-order stream)
     // device state
     uint16_t* d_input;
     const uint16_t* cur_input;
@@ -169,6 +173,9 @@ void musica_destroy(musica_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (void* p : c->allocations) hipFree(p);
+    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -198,7 +205,7 @@ musica_ctx* musica_create(const musica_params* params) {
     c->p.levels = L; c->p.batch = (uint32_t)c->B;
     c->generic = (params->flags & MUSICA_FLAG_GENERIC_KERNELS) != 0;
     c->tuning = false;
-    c->stream = nullptr; c->profiling = 0; c->spans_used = 0; c->cur_input = nullptr;
+    c->stream = nullptr; c->side = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr; c->profiling = 0; c->spans_used = 0; c->cur_input = nullptr;
     memset(c->prof_total_us, 0, sizeof(c->prof_total_us));
     memset(c->prof_count, 0, sizeof(c->prof_count));
     int s = (int)N;
@@ -227,6 +234,10 @@ musica_ctx* musica_create(const musica_params* params) {
 
     const size_t B = (size_t)c->B;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+    c->dag = env_int("MUSICA_DAG", 1) != 0;
     ok = ok && dalloc(c, &c->d_input, B * N * N);
     ok = ok && dalloc(c, &c->d_minmax, B * kMinMaxStride);
     ok = ok && dalloc(c, &c->d_norm, B * c->lv[0].plane);
@@ -262,6 +273,7 @@ musica_ctx* musica_create(const musica_params* params) {
         return nullptr;
     }
     c->cur_input = c->d_input;
+    c->cur = c->stream;
     for (int i = 0; i < c->L; i++) {
         c->rows_reduce[i] = pick_rows(c->reduce_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
         c->rows_band[i] = pick_rows(c->band_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
@@ -283,7 +295,8 @@ uint32_t musica_get_level_size(const musica_ctx* c, uint32_t level) { return (c 
 struct Span {
     musica_ctx* c;
     ProfSpan* s;
-    Span(musica_ctx* ctx, int id) : c(ctx), s(nullptr) {
+    hipStream_t st;
+    Span(musica_ctx* ctx, int id) : c(ctx), s(nullptr), st(ctx->cur) {
         if (!((c->profiling >> id) & 1u)) return;
         if (c->spans_used == c->spans.size()) {
             ProfSpan n;
@@ -294,10 +307,10 @@ struct Span {
         }
         s = &c->spans[c->spans_used++];
         s->id = id;
-        hipEventRecord(s->a, c->stream);
+        hipEventRecord(s->a, st);
     }
     ~Span() {
-        if (s) hipEventRecord(s->b, c->stream);
+        if (s) hipEventRecord(s->b, st);
     }
 };
 
@@ -322,13 +335,13 @@ static void enqueue_norm(musica_ctx* c) {
 }
 
 static void run_reduce_level(musica_ctx* c, int i, int rows) {
-    launch_reduce(c->stream, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, rows, c->generic, c->reduce_trip, c->tuning ? 3 : (i == 0 ? 0 : 1));
+    launch_reduce(c->cur, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, rows, c->generic, c->reduce_trip, c->tuning ? 3 : (i == 0 ? 0 : 1));
 }
 static void run_band_level(musica_ctx* c, int i, int rows) {
-    launch_band(c->stream, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, rows, c->generic, c->band_trip);
+    launch_band(c->cur, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, rows, c->generic, c->band_trip);
 }
 static void run_sdev_level(musica_ctx* c, int i, int rows) {
-    launch_sdev_hist(c->stream, c->d_band[i], c->d_sdev[i], c->lv[i], c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS,
+    launch_sdev_hist(c->cur, c->d_band[i], c->d_sdev[i], c->lv[i], c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS,
                      (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov, c->B, rows);
 }
 
@@ -418,7 +431,49 @@ static void enqueue_gradation(musica_ctx* c) {
     { Span sp(c, MUSICA_KERNEL_GRAD_APPLY); launch_grad_apply(c->stream, c->d_recon[0], c->d_graded, l0, c->d_gcurve, c->B); }
 }
 
+// Two-stream form of the dispatch script. The reference submits everything to one in-order queue;
+// the data dependences allow more: once level 0 is smoothed (R0), the whole coarse chain
+// R1 B1 S1 R2 B2 S2 ... (small, launch- and latency-bound kernels) is independent of the two big
+// level-0 kernels B0 and S0, so it runs on a second stream underneath them and rejoins before the
+// curves are generated. Same kernels, same arguments, same results.
+static void enqueue_dag(musica_ctx* c) {
+    c->cur = c->stream;
+    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B);  // :2153-2162
+    enqueue_norm(c);
+    { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_level(c, 0, c->rows_reduce[0]); }
+    hipEventRecord(c->ev_fork, c->stream);
+    hipStreamWaitEvent(c->side, c->ev_fork, 0);
+    c->cur = c->side;
+    for (int i = 1; i < c->L; i++) {
+        { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
+        { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
+        if (i <= MUSICA_CNR_LEVEL) { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
+    }
+    hipEventRecord(c->ev_join, c->side);
+    c->cur = c->stream;
+    { Span sp(c, MUSICA_KERNEL_BAND_L0); run_band_level(c, 0, c->rows_band[0]); }
+    { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, 0, c->rows_sdev[0]); }
+    hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    {
+        Span sp(c, MUSICA_KERNEL_CURVES);
+        launch_noise_curves(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts);
+    }
+    {
+        Span sp(c, MUSICA_KERNEL_CNR);
+        launch_cnr(c->stream, c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_noise_max, c->L, c->B);
+    }
+    enqueue_expand(c);
+    enqueue_gradation(c);
+}
+
 static int enqueue_all(musica_ctx* c) {
+    if (c->dag && !c->tuning) {
+        enqueue_dag(c);
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e0));
+        return 1;
+    }
+    c->cur = c->stream;
     launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B);  // :2153-2162
     enqueue_norm(c);
     enqueue_reduce(c);
@@ -466,6 +521,7 @@ static void autotune(musica_ctx* c) {
             }
     if (hipMemcpy(c->d_input, px.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) return;
     c->cur_input = c->d_input;
+    c->cur = c->stream;
     if (!enqueue_all(c)) return;
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -561,6 +617,7 @@ int musica_execute(musica_ctx* c, const uint16_t* pixels) {
 
 int musica_debug_run_stage(musica_ctx* c, musica_stage stage) {
     CHECK_CTX(c);
+    c->cur = c->stream;
     switch (stage) {
         case MUSICA_STAGE_NORM:
             launch_clear(c->stream, c->d_minmax, nullptr, nullptr, nullptr, c->B);

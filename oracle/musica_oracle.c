@@ -267,6 +267,7 @@ void musica_oracle_k_noise_hist(const float* sdev, uint32_t side, uint32_t group
                 for (int n = 0; n < HIST_AREA; n++) {
                     float cur = ld(sdev, (int)side, bx + m, by + n);  /* :22-23 */
                     if (cur == 0.0f) break;                            /* :29 */
+                    if (cur != cur) break;                             /* int(NaN) undefined: restated as bin 0 -> break (:39) */
                     float adj = cur / MAX_NOISE_VALUE;                 /* :31 */
                     if (adj > 1.0f) break;                             /* :33 */
                     int bin = (int)(adj * (float)MUSICA_NOISE_BINS + 0.5f); /* :35 */
