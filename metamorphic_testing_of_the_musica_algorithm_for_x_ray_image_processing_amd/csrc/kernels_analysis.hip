@@ -243,7 +243,7 @@ __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const S
         for (int j = 0; j < 8; j++) {
             const int x = g.c + j;
             const float cur = (j < g.valid && x < cov) ? s[j] : 0.0f;
-            const int bin = musica_noise_bin(cur);                         // 0 = break (:29, :33, :39); exact (exact_math.h)
+            const int bin = musica_noise_bin(cur);                           // 0 = break (:29, :33, :39); exact (exact_math.h)
             const bool live = (alive >> j) & 1u;
             if (bin == 0) alive &= ~(1u << j);
             const bool add = live && bin > 0 && bin < MUSICA_NOISE_BINS;    // bin 2048 is dropped (Q1) but does not break

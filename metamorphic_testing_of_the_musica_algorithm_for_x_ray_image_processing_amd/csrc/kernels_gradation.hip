@@ -50,6 +50,10 @@ __device__ __forceinline__ CnrClass classify_cnr(float c) {
     return k;
 }
 
+// SHARED8: the cnr scale is a multiple of 8 (always the case for N >= 57: scale = ceil(N / ceil(N/8)) = 8), so
+// the 4 columns of a lane and each half (8 rows) of a 16-row group sit under ONE cnr texel: two cnr loads
+// and two classifications per lane and group instead of 64.
+template <bool SHARED8>
 __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
     __shared__ uint32_t lh[MUSICA_GRAD_BINS + 64];  // + one scratch word per lane for the branch-free adds
     for (int i = threadIdx.x; i < MUSICA_GRAD_BINS + 64; i += blockDim.x) lh[i] = 0u;
@@ -57,20 +61,21 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
     const int img = blockIdx.z;
     const Buf ib = make_buf(a.img + (size_t)img * a.plane, a.plane * 4);
     const Buf nb = make_buf(a.normalized + (size_t)img * a.plane, a.plane * 4);
-    const float* cn = a.cnr + (size_t)img * a.cnrPlane;
+    const Buf cb = make_buf(a.cnr + (size_t)img * a.cnrPlane, a.cnrPlane * 4);
     const int lane = threadIdx.x & 63;
     const int N = a.N;
     const int c = blockIdx.x * 256 + lane * 4;
     const int valid = min(max(N - c, 0), 4);                  // in-image columns among the lane's 4
     const uint32_t coff = c < N ? (uint32_t)c * 4u : kOob;
-    const uint32_t rb = (uint32_t)a.pitch * 4u;
+    const uint32_t rb = (uint32_t)a.pitch * 4u, crb = (uint32_t)a.cnrPitch * 4u;
     const int mbase = (lane & 3) * 4;
     const uint32_t border = 100u, lim = (uint32_t)N - border;  // uint arithmetic of img_relevant.comp:46-49
     bool colin[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) colin[j] = (uint32_t)(c + j) > border && (uint32_t)(c + j) < lim;
-    // the lane's 4 columns sit under one cnr texel when the scale is a multiple of 4 (c % 4 == 0)
-    const bool shared_cnr = (a.cnrScale & 3) == 0;
+    // byte offset of the lane's cnr column (out of the cnr image reads 0, Q1)
+    const int cx0 = c / a.cnrScale;
+    const uint32_t cxoff = (c < N && cx0 < a.cnrS) ? (uint32_t)cx0 * 4u : kOob;
     const int g0 = (blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)) * a.groups_per_wave;
     for (int gi = 0; gi < a.groups_per_wave; gi++) {
         const int yb = (g0 + gi) * kHistArea;
@@ -107,6 +112,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
                 const int y = yb + half * 8 + n;
                 pn[n] = bload4(nb, (y < N ? (uint32_t)y * rb : kOob) + coff);
             }
+            CnrClass kc;
+            if (SHARED8) {
+                const int cy = (yb + half * 8) / a.cnrScale;   // wave-uniform
+                kc = classify_cnr(bload1(cb, (cy < a.cnrS ? (uint32_t)cy * crb : kOob) + cxoff) * kMaxCnrValue);
+            }
 #pragma unroll
             for (int n8 = 0; n8 < 8; n8++) {
                 const int n = half * 8 + n8;
@@ -114,10 +124,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
                 const bool rowin = (uint32_t)y > border && (uint32_t)y < lim;
                 const float vv[4] = {v[n].x, v[n].y, v[n].z, v[n].w};
                 const float pp[4] = {pn[n8].x, pn[n8].y, pn[n8].z, pn[n8].w};
-                CnrClass kc = classify_cnr(shared_cnr ? cnr_at(cn, a.cnrS, a.cnrPitch, a.cnrScale, min(c, N - 1), min(y, N - 1)) : 0.0f);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    if (!shared_cnr) kc = classify_cnr(cnr_at(cn, a.cnrS, a.cnrPitch, a.cnrScale, min(c + j, N - 1), min(y, N - 1)));
+                    if (!SHARED8) {
+                        const int cx = (c + j) / a.cnrScale, cy = y / a.cnrScale;
+                        const uint32_t off = (c + j < N && y < N && cx < a.cnrS && cy < a.cnrS) ? (uint32_t)cy * crb + (uint32_t)cx * 4u : kOob;
+                        kc = classify_cnr(bload1(cb, off) * kMaxCnrValue);
+                    }
                     const float cur = vv[j];
                     const float scaled = cur * (float)MUSICA_GRAD_BINS;                // gradation_histogram.comp:26
                     // NaN never indexes (oracle Q6); bins outside [0, 1024) are dropped (Q1)
@@ -300,7 +313,9 @@ void launch_grad_hist(hipStream_t st, const GradArgs& a, int batch) {
     const int col_blocks = (a.N + 255) / 256;
     const int groups = (a.N + kHistArea - 1) / kHistArea;
     const int wave_rows = (groups + a.groups_per_wave - 1) / a.groups_per_wave;
-    hipLaunchKernelGGL(k_grad_hist, dim3(col_blocks, (wave_rows + kWavesPerBlock - 1) / kWavesPerBlock, batch), dim3(kBlockThreads), 0, st, a);
+    const dim3 grid(col_blocks, (wave_rows + kWavesPerBlock - 1) / kWavesPerBlock, batch);
+    if ((a.cnrScale & 7) == 0) hipLaunchKernelGGL(k_grad_hist<true>, grid, dim3(kBlockThreads), 0, st, a);
+    else hipLaunchKernelGGL(k_grad_hist<false>, grid, dim3(kBlockThreads), 0, st, a);
 }
 
 void launch_grad_hist_ref(hipStream_t st, const float* img, const float* relevant, const LevelDesc& l0, uint32_t* hist, int batch) {
