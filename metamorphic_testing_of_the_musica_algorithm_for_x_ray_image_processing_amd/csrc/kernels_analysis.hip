@@ -174,23 +174,34 @@ __device__ __forceinline__ SCfg make_scfg(int strip, int lane, int S) {
 }
 
 // row_off = kOob for rows outside the image. Columns >= S inside the last 16-byte group and the odd
-// right-halo column are masked to 0 by `valid` / `right_valid`.
-__device__ __forceinline__ void load_srow(SRow& r, const Buf& b, uint32_t row_off, const SCfg& g, int S) {
+// right-halo column are masked to 0 by `valid` / the c+9 test when the row is squared.
+struct SRaw {
+    float4 a, d;
+    float2 l, h;
+};
+__device__ __forceinline__ void load_sraw(SRaw& r, const Buf& b, uint32_t row_off, const SCfg& g) {
     // kOob has only bit 31 set and every in-image offset is < 2^31, so an OR keeps "either one out of range" out of range
-    const float4 a = bload4(b, (g.off0 + row_off) | ((g.off0 | row_off) & kOob));
-    const float4 d = bload4(b, (g.off1 + row_off) | ((g.off1 | row_off) & kOob));
-    const float2 l = bload2(b, (g.off_l + row_off) | ((g.off_l | row_off) & kOob));
-    const float2 h = bload2(b, (g.off_r + row_off) | ((g.off_r | row_off) & kOob));
-    float v[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
+    r.a = bload4(b, (g.off0 + row_off) | ((g.off0 | row_off) & kOob));
+    r.d = bload4(b, (g.off1 + row_off) | ((g.off1 | row_off) & kOob));
+    r.l = bload2(b, (g.off_l + row_off) | ((g.off_l | row_off) & kOob));
+    r.h = bload2(b, (g.off_r + row_off) | ((g.off_r | row_off) & kOob));
+}
+__device__ __forceinline__ void square_srow(SRow& r, const SRaw& w, const SCfg& g, int S) {
+    const float v[8] = {w.a.x, w.a.y, w.a.z, w.a.w, w.d.x, w.d.y, w.d.z, w.d.w};
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const float t = j < g.valid ? v[j] : 0.0f;
         r.q[j] = t * t;
     }
-    r.l0 = l.x * l.x; r.l1 = l.y * l.y;
-    r.h0 = h.x * h.x;
-    const float h1 = (g.c + 9 < S) ? h.y : 0.0f;
+    r.l0 = w.l.x * w.l.x; r.l1 = w.l.y * w.l.y;
+    r.h0 = w.h.x * w.h.x;
+    const float h1 = (g.c + 9 < S) ? w.h.y : 0.0f;
     r.h1 = h1 * h1;
+}
+__device__ __forceinline__ void load_srow(SRow& r, const Buf& b, uint32_t row_off, const SCfg& g, int S) {
+    SRaw w;
+    load_sraw(w, b, row_off, g);
+    square_srow(r, w, g, S);
 }
 
 __device__ __forceinline__ float sum5(float a, float b, float c, float d, float e) {
@@ -289,6 +300,49 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist(const float* __rest
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) w[i] = w[T + i];
+        }
+    }
+    __syncthreads();
+    uint32_t* gh = hist + (size_t)img * hist_stride;
+    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS; i += blockDim.x) {
+        const uint32_t v = lh[i];
+        if (v) atomicAdd(&gh[i], v);
+    }
+}
+
+// Software-pipelined form: one row per trip; the raw row of trip y+1 is requested before trip y is
+// computed and squared only when it enters the window (so the request never blocks the arithmetic).
+template <bool HIST>
+__global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
+                                                                size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov,
+                                                                int rows_per_wave) {
+    __shared__ uint32_t lh[MUSICA_NOISE_BINS + 64];
+    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS + 64; i += blockDim.x) lh[i] = 0u;
+    __syncthreads();
+    const int img = blockIdx.z;
+    const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
+    sdev += (size_t)img * plane;
+    const int lane = threadIdx.x & 63;
+    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int y0 = seg * rows_per_wave;
+    const SCfg g = make_scfg(blockIdx.x, lane, S);
+    const uint32_t rb = (uint32_t)pitch * 4u;
+    auto roff = [&](int row) -> uint32_t { return (row >= 0 && row < S) ? (uint32_t)row * rb : kOob; };
+    if (y0 < S) {
+        const int y1 = min(y0 + rows_per_wave, S);
+        SRow w0, w1, w2, w3, w4;
+        SRaw raw;
+        load_srow(w0, bb, roff(y0 - 2), g, S);
+        load_srow(w1, bb, roff(y0 - 1), g, S);
+        load_srow(w2, bb, roff(y0), g, S);
+        load_srow(w3, bb, roff(y0 + 1), g, S);
+        load_sraw(raw, bb, roff(y0 + 2), g);
+        uint32_t alive = 0;
+        for (int y = y0; y < y1; y++) {
+            square_srow(w4, raw, g, S);
+            load_sraw(raw, bb, roff(y + 3), g);  // rows past the image carry an out-of-range offset: no access
+            sdev_row<HIST>(w0, w1, w2, w3, w4, g, S, y, cov, sdev + (size_t)y * pitch, lh, alive);
+            w0 = w1; w1 = w2; w2 = w3; w3 = w4;
         }
     }
     __syncthreads();
@@ -526,7 +580,8 @@ void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const Leve
     if (dbg == 1) hipLaunchKernelGGL((k_sdev_hist<4, false>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
     else if (dbg == 2) hipLaunchKernelGGL((k_sdev_hist<1, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
     else if (dbg == 3) hipLaunchKernelGGL((k_sdev_hist<2, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
-    else hipLaunchKernelGGL((k_sdev_hist<4, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
+    else if (dbg == 4) hipLaunchKernelGGL((k_sdev_hist<4, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
+    else hipLaunchKernelGGL((k_sdev_hist_pf<true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
 }
 
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch) {

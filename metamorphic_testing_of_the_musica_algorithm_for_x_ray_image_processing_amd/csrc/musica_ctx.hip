@@ -398,7 +398,7 @@ static bool uses_nr(int lvl) { return lvl < MUSICA_CNR_LEVEL - 1; }  // currentL
 static void run_expand_level(musica_ctx* c, int lvl, int rows) {
     ExpandArgs a = expand_args(c, lvl, c->d_recon[lvl]);
     a.rows_per_wave = rows;
-    launch_expand(c->stream, a, gain_mode(lvl), uses_nr(lvl), c->B, c->generic, c->expand_trip);
+    launch_expand(c->cur, a, gain_mode(lvl), uses_nr(lvl), c->B, c->generic, c->expand_trip);
 }
 
 // stages "aply" + "exp" (src/vk_processing.cpp:2361-2431)
@@ -437,22 +437,34 @@ static void enqueue_gradation(musica_ctx* c) {
 // level-0 kernels B0 and S0, so it runs on a second stream underneath them and rejoins before the
 // curves are generated. Same kernels, same arguments, same results.
 static void enqueue_dag(musica_ctx* c) {
+    const int L = c->L;
     c->cur = c->stream;
     launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B);  // :2153-2162
     enqueue_norm(c);
     { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_level(c, 0, c->rows_reduce[0]); }
+    { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, 1, c->rows_reduce[1]); }
     hipEventRecord(c->ev_fork, c->stream);
     hipStreamWaitEvent(c->side, c->ev_fork, 0);
+    // side stream: everything of levels >= 2 that does not need a histogram-derived curve —
+    // reduce / band / sdev of levels 2.., then the expand slots of levels L-1 .. 3 (constant gain above
+    // level 3, range gain at level 3: neither reads a curve, src/vk_processing.cpp:259-293)
     c->cur = c->side;
-    for (int i = 1; i < c->L; i++) {
+    for (int i = 2; i < L; i++) {
         { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
         { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
         if (i <= MUSICA_CNR_LEVEL) { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
     }
+    for (int lvl = L - 1; lvl >= MUSICA_CNR_LEVEL; lvl--) {
+        Span sp(c, MUSICA_KERNEL_EXPAND_REST);
+        run_expand_level(c, lvl, c->rows_expand[lvl]);
+    }
     hipEventRecord(c->ev_join, c->side);
+    // main stream: the bandwidth-bound kernels of levels 0 and 1
     c->cur = c->stream;
     { Span sp(c, MUSICA_KERNEL_BAND_L0); run_band_level(c, 0, c->rows_band[0]); }
     { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, 0, c->rows_sdev[0]); }
+    { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, 1, c->rows_band[1]); }
+    { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, 1, c->rows_sdev[1]); }
     hipStreamWaitEvent(c->stream, c->ev_join, 0);
     {
         Span sp(c, MUSICA_KERNEL_CURVES);
@@ -462,7 +474,10 @@ static void enqueue_dag(musica_ctx* c) {
         Span sp(c, MUSICA_KERNEL_CNR);
         launch_cnr(c->stream, c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_noise_max, c->L, c->B);
     }
-    enqueue_expand(c);
+    for (int lvl = MUSICA_CNR_LEVEL - 1; lvl >= 0; lvl--) {
+        Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
+        run_expand_level(c, lvl, c->rows_expand[lvl]);
+    }
     enqueue_gradation(c);
 }
 
