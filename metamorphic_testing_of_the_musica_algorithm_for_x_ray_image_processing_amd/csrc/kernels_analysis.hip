@@ -428,34 +428,42 @@ __global__ __launch_bounds__(256) void k_noise_curves(const uint32_t* __restrict
         if (k) { mp.maxValue = (uint32_t)(k >> 32); mp.maxBin = 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull); }
     }
     DevCurve* c = curves + (size_t)img * levels + level;
-    if (threadIdx.x == 0) {
-    maxpts[(size_t)img * levels + level] = mp;
+    __shared__ float cx[kCurveCap], cy[kCurveCap];
+    __shared__ int s_mono;
+    if (threadIdx.x == 0) maxpts[(size_t)img * levels + level] = mp;
+    // contrast_curve_generate.comp:56-94, one thread per curve point
     const float low = cparams[level].lowContrastFactor, high = cparams[level].highContrastFactor;
-    uint32_t n = 0;
-    if (low == 1.0f) {                                                                      // contrast_curve_generate.comp:59
-        c->x[0] = 0.0f; c->y[0] = high;                                                     // :68
-        c->x[1] = 1.0f; c->y[1] = high;                                                     // :69
-        n = 2;
-    } else {
-        const float p = (float)mp.maxBin * (1.0f / (float)MUSICA_NOISE_BINS) * kMaxNoiseValue;  // :71
-        generate_curve(c, n, 0.0f, 1.0f, p * 4.0f / 5.0f, low, p, low, 11);                                   // :72-76
-        generate_curve(c, n, p, low, p * 6.0f / 5.0f, low, p * 7.0f / 5.0f, low * 4.0f / 5.0f, 11);           // :77-81
-        generate_curve(c, n, p * 7.0f / 5.0f, low * 4.0f / 5.0f, p * 2.0f, 1.0f, 1.0f, 1.0f, 11);             // :82-86
+    const bool constant = (low == 1.0f);                                                       // :59
+    const int npts = constant ? 2 : 33;
+    if ((int)threadIdx.x < kCurveCap) {
+        const int i = threadIdx.x;
+        float x = 0.0f, y = 0.0f;
+        if (constant) {
+            if (i == 0) { x = 0.0f; y = high; }                                                 // :68
+            if (i == 1) { x = 1.0f; y = high; }                                                 // :69
+        } else if (i < 33) {
+            const float p = (float)mp.maxBin * (1.0f / (float)MUSICA_NOISE_BINS) * kMaxNoiseValue;  // :71
+            const int seg = i / 11;
+            const uint32_t k = (uint32_t)(i - seg * 11);
+            if (seg == 0) bezier_point(0.0f, 1.0f, p * 4.0f / 5.0f, low, p, low, k, x, y);                               // :72-76
+            else if (seg == 1) bezier_point(p, low, p * 6.0f / 5.0f, low, p * 7.0f / 5.0f, low * 4.0f / 5.0f, k, x, y);   // :77-81
+            else bezier_point(p * 7.0f / 5.0f, low * 4.0f / 5.0f, p * 2.0f, 1.0f, 1.0f, 1.0f, k, x, y);                   // :82-86
+        }
+        cx[i] = x;
+        cy[i] = y;
     }
-    c->count = n;
-    c->t0 = c->ta = c->t1 = 0.0f;
-    curve_finish(c);
-    }
+    __syncthreads();
+    curve_store_parallel(c, cx, cy, &s_mono, npts, 0.0f, 0.0f, 0.0f);
     if (level >= MUSICA_COARSER_LEVELS_START) return;   // only the 33-point curves get a lookup table (block-uniform)
-    __syncthreads();                                    // thread 0's curve is visible to the block
+    __syncthreads();
     // ---- bucket table for the expand kernel (see DevCurveLut) ----
     DevCurveLut* lut = luts + (size_t)img * MUSICA_COARSER_LEVELS_START + level;
-    const int count = (int)c->count;
-    const float range = c->x[kLutTailFirst - 1] * 1.25f;              // 1.75 p: above x[22] = 1.4 p, below x[23] >= 1.49 p + 0.01
+    const int count = npts;
+    const float range = cx[kLutTailFirst - 1] * 1.25f;                // 1.75 p: above x[22] = 1.4 p, below x[23] >= 1.49 p + 0.01
     const float inv_w = (float)kLutBuckets / range;
-    if (threadIdx.x == 0) sok = (c->monotone && count == 33 && range > 0.0f && inv_w < 3.0e38f) ? 1 : 0;
+    if (threadIdx.x == 0) sok = (s_mono && count == 33 && range > 0.0f && inv_w < 3.0e38f) ? 1 : 0;
     if ((int)threadIdx.x < kCurveCap) {
-        const float x = c->x[threadIdx.x];
+        const float x = cx[threadIdx.x];
         sx[threadIdx.x] = x;
         const float kf = x * inv_w;
         sbucket[threadIdx.x] = ((int)threadIdx.x < count && kf < (float)kLutBuckets) ? (int)kf : kLutBuckets;

@@ -214,4 +214,43 @@ __device__ __forceinline__ void generate_curve(DevCurve* c, uint32_t& n, float s
     }
 }
 
+// One point of generateCurve() (same arithmetic as generate_curve above): step k of the quadratic Bezier
+// (s, m, e), t = k / 10.
+__device__ __forceinline__ void bezier_point(float sx, float sy, float mx, float my, float ex, float ey, uint32_t k, float& x, float& y) {
+    const float t = (float)k / 10.0f;
+    const float xa = interpolate(sx, mx, t);
+    const float ya = interpolate(sy, my, t);
+    const float xb = interpolate(mx, ex, t);
+    const float yb = interpolate(my, ey, t);
+    x = interpolate(xa, xb, t);
+    y = interpolate(ya, yb, t);
+}
+
+// Block-parallel curve_finish(): threads 0 .. kCurveCap-1 hold point i in (x, y) (zeros at i >= count) and
+// have published them in sx / sy (LDS); fills slopes + monotone flag and writes the curve. Must be called by
+// every thread of the block (contains barriers).
+__device__ __forceinline__ void curve_store_parallel(DevCurve* c, const float* sx, const float* sy, int* s_mono, int count, float t0, float ta, float t1) {
+    const int i = threadIdx.x;
+    if (i == 0) *s_mono = 1;
+    __syncthreads();
+    if (i < kCurveCap) {
+        float m = 0.0f;
+        if (i + 1 < count) {
+            m = (sy[i + 1] - sy[i]) / (sx[i + 1] - sx[i]);   // linearFunction slope, contrast_curve_apply.comp:22-25
+            if (!(sx[i] <= sx[i + 1])) *s_mono = 0;
+        }
+        if (i == 0 && count > 0 && !(sx[0] == sx[0])) *s_mono = 0;
+        c->x[i] = sx[i];
+        c->y[i] = sy[i];
+        c->m[i] = m;
+    }
+    __syncthreads();
+    if (i == 0) {
+        c->count = (uint32_t)count;
+        c->monotone = (*s_mono && count <= 63) ? 1u : 0u;
+        c->t0 = t0; c->ta = ta; c->t1 = t1;
+        c->pad = 0;
+    }
+}
+
 }  // namespace musica

@@ -255,7 +255,9 @@ __global__ __launch_bounds__(1024) void k_grad_curve(const uint32_t* __restrict_
     // fail1 = lowest bin in [maxPosition, 1023] with count == 0 (1024 if none): max of (1024 - i).
     unsigned long long f1 = (i >= maxPosition && count == 0u) ? (unsigned long long)(MUSICA_GRAD_BINS - i) : 0ull;
     f1 = block_max_u64g(f1, s64);
-    if (i != 0) return;
+    __shared__ float cx[kCurveCap], cy[kCurveCap];
+    __shared__ int s_mono;
+    // the window scalars are block-uniform: every thread derives them (same arithmetic as one thread would)
     const uint32_t fail0 = (uint32_t)f0;
     const uint32_t fail1 = f1 ? (uint32_t)(MUSICA_GRAD_BINS - f1) : (uint32_t)MUSICA_GRAD_BINS;
     float t0 = 0.0f, t1 = 0.0f;
@@ -269,17 +271,19 @@ __global__ __launch_bounds__(1024) void k_grad_curve(const uint32_t* __restrict_
     if (t1 > 1.0f) t1 = 1.0f;                                                    // :144
     float tf = -(0.5f / m) + ta;                                                 // :146
     if (tf < t0) tf = t0;                                                        // :149
-    DevCurve* c = curves + img;
-    uint32_t n = 0;
-    c->x[n] = 0.0f; c->y[n] = 0.0f; n++;                                         // :152
-    generate_curve(c, n, t0, 0.0f, tf, 0.0f, ta, y_m, 10);                       // :156-160
     if (tf == t0) m = y_m / (ta - tf);                                           // :162-163
     const float ts = (y_m / m) + ta;                                             // :165
-    generate_curve(c, n, ta, y_m, ts, 1.0f, t1, 1.0f, 10);                       // :169-173
-    c->x[n] = 1.0f; c->y[n] = 1.0f; n++;                                         // :179
-    c->count = n;                                                                // :181
-    c->t0 = t0; c->ta = ta; c->t1 = t1;
-    curve_finish(c);
+    // 22 points, one thread each: (0,0), Bezier[(t0,0),(tf,0),(ta,.5)] i = 0..9, Bezier[(ta,.5),(ts,1),(t1,1)] i = 0..9, (1,1)
+    if (i < (uint32_t)kCurveCap) {
+        float x = 0.0f, y = 0.0f;
+        if (i >= 1 && i <= 10) bezier_point(t0, 0.0f, tf, 0.0f, ta, y_m, i - 1, x, y);        // :156-160
+        else if (i >= 11 && i <= 20) bezier_point(ta, y_m, ts, 1.0f, t1, 1.0f, i - 11, x, y); // :169-173
+        else if (i == 21) { x = 1.0f; y = 1.0f; }                                              // :179
+        cx[i] = x;
+        cy[i] = y;
+    }
+    __syncthreads();
+    curve_store_parallel(curves + img, cx, cy, &s_mono, 22, t0, ta, t1);                       // :181
 }
 
 // ---- K21 ------------------------------------------------------------------------------
