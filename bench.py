@@ -41,8 +41,10 @@ WORKLOADS = {
 }
 
 
-def algorithmic_bytes(n, levels, batch):
-    """Algorithmic HBM bytes per launch of each kernel family, f32 = 4 B, u16 = 2 B."""
+def algorithmic_bytes(n, levels, batch, fused_u16=True):
+    """Algorithmic HBM bytes per launch of each kernel family, f32 = 4 B, u16 = 2 B.
+    fused_u16: the level-0 kernels read the raw uint16 pixels (2 B/px) instead of a stored normalized image (4 B/px)."""
+    src = 2 if fused_u16 else 4
     s = [n]
     for _ in range(levels):
         s.append((s[-1] + 1) // 2)
@@ -51,15 +53,15 @@ def algorithmic_bytes(n, levels, batch):
     return {
         "minmax": 2 * p[0] * batch,
         "normalize": 6 * p[0] * batch,
-        "reduce_l0": (4 * p[0] + 4 * p[1]) * batch,                      # read S^2 f32 once, write (S/2)^2 once
+        "reduce_l0": (src * p[0] + 4 * p[1]) * batch,                    # read S^2 once (u16 when fused), write (S/2)^2 f32 once
         "reduce_rest": sum(4 * p[i] + 4 * p[i + 1] for i in rest) * batch / max(1, len(rest)),
-        "band_l0": (8 * p[0] + 4 * p[1]) * batch,                        # read fine + coarse, write band
+        "band_l0": ((src + 4) * p[0] + 4 * p[1]) * batch,                # read fine + coarse, write band
         "band_rest": sum(8 * p[i] + 4 * p[i + 1] for i in rest) * batch / max(1, len(rest)),
         "sdev_hist": sum(8 * p[i] for i in range(4)) * batch / 4.0,      # read band, write sdev (hist in LDS)
         "expand_l0": (12 * p[0] + 4 * p[1]) * batch,                     # read band + sdev + coarse, write recon
         "expand_rest": (sum(12 * p[i] + 4 * p[i + 1] for i in range(1, 4)) +
                         sum(8 * p[i] + 4 * p[i + 1] for i in range(4, levels))) * batch / max(1, len(rest)),
-        "grad_hist": 8 * p[0] * batch,                                   # read recon + normalized
+        "grad_hist": (4 + src) * p[0] * batch,                           # read recon + normalized (or raw)
         "grad_apply": 8 * p[0] * batch,                                  # read recon, write graded
         "curves": 4 * 2048 * 4 * batch,
         "cnr": 8 * p[3] * batch,
@@ -166,7 +168,8 @@ def main():
     if rank == 0:
         mpix = world * batch * n * n * args.steps / 1e6
         ms_per_step = elapsed / args.steps * 1e3
-        ab = algorithmic_bytes(n, levels, batch)
+        fused = (n % 8 == 0) and os.environ.get("MUSICA_U16", "1") != "0"
+        ab = algorithmic_bytes(n, levels, batch, fused)
         kernels = {}
         total_kernel_us = 0.0
         for name, (us, cnt) in prof.items():
@@ -189,7 +192,9 @@ def main():
                     traffic = json.load(open(tpath)).get(args.workload, {}).get("reduce_l0_hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roofline = {"kernel": "k_reduce_fast (5-tap smooth + 2x downsample, level 0, %d images of %dx%d per launch)" % (batch, n, n),
+            roofline = {"kernel": "%s (5-tap smooth + 2x downsample, level 0, %d images of %dx%d per launch; input read as %s)"
+                                  % ("k_reduce_u16_pf" if fused else "k_reduce_fast_pf", batch, n, n,
+                                     "raw uint16 normalised on the fly: 2 B/px in + 1 B/px out" if fused else "f32: 4 B/px in + 1 B/px out"),
                         "bound": "hbm", "achieved": k["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(k["alg_GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": ab["reduce_l0"], "mean_us": k["mean_us"]}

@@ -81,13 +81,6 @@ __global__ __launch_bounds__(256) void k_minmax_u16(const uint16_t* __restrict__
     }
 }
 
-// The two scalars img_normalize.comp:17-18 reads from the 1x1 ends of the chains.
-__device__ __forceinline__ void chain_scalars(const uint32_t* __restrict__ minmax, int img, int min_chain_exact, float& minv, float& maxv) {
-    const uint32_t mnu = minmax[kMinMaxStride * img], mxu = minmax[kMinMaxStride * img + kMaxWord];
-    maxv = (float)f2u(sqrtf((float)mxu));
-    minv = min_chain_exact ? (float)f2u(sqrtf((float)mnu)) : 0.0f;
-}
-
 // ---- K1 + K4 --------------------------------------------------------------------------
 // out = (sqrt(float(px)) - min) / (max - min), unclamped (img_normalize.comp:24-27).
 // Vector path: 8 pixels per thread when N % 8 == 0 (dense u16 rows and pitched f32 rows both 16-byte aligned).

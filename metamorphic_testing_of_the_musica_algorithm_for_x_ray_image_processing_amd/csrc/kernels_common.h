@@ -105,6 +105,27 @@ __device__ __forceinline__ uint32_t f2u(float v) {
     return (uint32_t)v;
 }
 
+// The two scalars img_normalize.comp:17-18 reads from the 1x1 ends of the min / max chains, from the
+// integer extrema k_minmax_u16 left in `minmax` (see kernels_analysis.hip).
+__device__ __forceinline__ void chain_scalars(const uint32_t* __restrict__ minmax, int img, int min_chain_exact, float& minv, float& maxv) {
+    const uint32_t mnu = minmax[kMinMaxStride * img], mxu = minmax[kMinMaxStride * img + kMaxWord];
+    maxv = (float)f2u(sqrtf((float)mxu));
+    minv = min_chain_exact ? (float)f2u(sqrtf((float)mnu)) : 0.0f;
+}
+// img_sqrt.comp:15 + img_normalize.comp:24 for one raw pixel (den = max - min).
+__device__ __forceinline__ float norm_px(uint32_t v, float minv, float den) { return (sqrtf((float)v) - minv) / den; }
+// Largest raw value whose normalized value is <= 0.90 (img_relevant.comp:56), -1 if there is none. norm_px is
+// non-decreasing in v (sqrt, subtraction and division by den >= 0 are monotone; den == 0 gives inf / NaN, for
+// which the comparison is false for every v), so `normalized <= 0.9` is exactly `raw <= threshold`.
+__device__ __forceinline__ int norm_threshold_090(float minv, float den) {
+    int lo = -1, hi = 65535;  // invariant: P(lo) true (or lo == -1), P(hi + 1) false
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (norm_px((uint32_t)mid, minv, den) <= 0.90f) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 // 16-byte load of 4 consecutive floats of a row; columns >= valid_cols come back as 0.
 // `row` must be 16-byte aligned at column x (x % 4 == 0) and x < pitch.
 __device__ __forceinline__ float4 load4_guard(const float* __restrict__ row, int x, int valid_cols) {

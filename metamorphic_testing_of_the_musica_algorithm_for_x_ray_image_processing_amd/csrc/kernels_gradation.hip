@@ -53,14 +53,25 @@ __device__ __forceinline__ CnrClass classify_cnr(float c) {
 // SHARED8: the cnr scale is a multiple of 8 (always the case for N >= 57: scale = ceil(N / ceil(N/8)) = 8), so
 // the 4 columns of a lane and each half (8 rows) of a 16-row group sit under ONE cnr texel: two cnr loads
 // and two classifications per lane and group instead of 64.
-template <bool SHARED8>
+// RAW: `normalized <= 0.9` (img_relevant.comp:56) is tested on the raw uint16 pixel against the per-image
+// threshold norm_threshold_090() — exact, because the normalisation is monotone — so the kernel reads
+// 2 B/px of raw input instead of a stored 4 B/px normalized image.
+template <bool SHARED8, bool RAW>
 __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
     __shared__ uint32_t lh[MUSICA_GRAD_BINS + 64];  // + one scratch word per lane for the branch-free adds
+    __shared__ int s_thr;
     for (int i = threadIdx.x; i < MUSICA_GRAD_BINS + 64; i += blockDim.x) lh[i] = 0u;
-    __syncthreads();
     const int img = blockIdx.z;
+    if (RAW && threadIdx.x == 0) {
+        float minv, maxv;
+        chain_scalars(a.minmax, img, a.min_chain_exact, minv, maxv);
+        s_thr = norm_threshold_090(minv, maxv - minv);
+    }
+    __syncthreads();
+    const int thr = RAW ? s_thr : 0;
     const Buf ib = make_buf(a.img + (size_t)img * a.plane, a.plane * 4);
-    const Buf nb = make_buf(a.normalized + (size_t)img * a.plane, a.plane * 4);
+    const Buf nb = RAW ? make_buf(a.raw + (size_t)img * a.N * a.N, (size_t)a.N * a.N * 2)
+                       : make_buf(a.normalized + (size_t)img * a.plane, a.plane * 4);
     const Buf cb = make_buf(a.cnr + (size_t)img * a.cnrPlane, a.cnrPlane * 4);
     const int lane = threadIdx.x & 63;
     const int N = a.N;
@@ -68,6 +79,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
     const int valid = min(max(N - c, 0), 4);                  // in-image columns among the lane's 4
     const uint32_t coff = c < N ? (uint32_t)c * 4u : kOob;
     const uint32_t rb = (uint32_t)a.pitch * 4u, crb = (uint32_t)a.cnrPitch * 4u;
+    const uint32_t ucoff = c < N ? (uint32_t)c * 2u : kOob, urb = (uint32_t)N * 2u;   // dense uint16 rows (RAW; N % 4 == 0)
     const int mbase = (lane & 3) * 4;
     const uint32_t border = 100u, lim = (uint32_t)N - border;  // uint arithmetic of img_relevant.comp:46-49
     bool colin[4];
@@ -107,10 +119,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             float4 pn[8];
+            float2 pr[8];
 #pragma unroll
             for (int n = 0; n < 8; n++) {
                 const int y = yb + half * 8 + n;
-                pn[n] = bload4(nb, (y < N ? (uint32_t)y * rb : kOob) + coff);
+                if (RAW) pr[n] = bload2(nb, (y < N ? (uint32_t)y * urb : kOob) + ucoff);
+                else pn[n] = bload4(nb, (y < N ? (uint32_t)y * rb : kOob) + coff);
             }
             CnrClass kc;
             if (SHARED8) {
@@ -123,7 +137,14 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
                 const int y = yb + n;
                 const bool rowin = (uint32_t)y > border && (uint32_t)y < lim;
                 const float vv[4] = {v[n].x, v[n].y, v[n].z, v[n].w};
-                const float pp[4] = {pn[n8].x, pn[n8].y, pn[n8].z, pn[n8].w};
+                bool le090[4];
+                if (RAW) {
+                    const uint32_t r0 = __float_as_uint(pr[n8].x), r1 = __float_as_uint(pr[n8].y);
+                    le090[0] = (int)(r0 & 0xFFFFu) <= thr; le090[1] = (int)(r0 >> 16) <= thr;
+                    le090[2] = (int)(r1 & 0xFFFFu) <= thr; le090[3] = (int)(r1 >> 16) <= thr;
+                } else {
+                    le090[0] = pn[n8].x <= 0.90f; le090[1] = pn[n8].y <= 0.90f; le090[2] = pn[n8].z <= 0.90f; le090[3] = pn[n8].w <= 0.90f;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (!SHARED8) {
@@ -136,7 +157,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
                     // NaN never indexes (oracle Q6); bins outside [0, 1024) are dropped (Q1)
                     const bool inrange = scaled > -1.0f && scaled < (float)MUSICA_GRAD_BINS;   // int(scaled) in [0, 1023]
                     const int bin = inrange ? (int)scaled : 0;
-                    const uint32_t w = (rowin && colin[j]) ? (kc.ramp ? kc.w_ramp : ((kc.high && pp[j] <= 0.90f) ? 100u : 0u)) : 0u;  // :28-30
+                    const uint32_t w = (rowin && colin[j]) ? (kc.ramp ? kc.w_ramp : ((kc.high && le090[j]) ? 100u : 0u)) : 0u;  // :28-30
                     const bool add = inrange && ((mbase + j) * 16 + n < q) && w != 0u;
                     atomicAdd(&lh[add ? bin : MUSICA_GRAD_BINS + lane], add ? w : 0u);
                 }
@@ -318,8 +339,14 @@ void launch_grad_hist(hipStream_t st, const GradArgs& a, int batch) {
     const int groups = (a.N + kHistArea - 1) / kHistArea;
     const int wave_rows = (groups + a.groups_per_wave - 1) / a.groups_per_wave;
     const dim3 grid(col_blocks, (wave_rows + kWavesPerBlock - 1) / kWavesPerBlock, batch);
-    if ((a.cnrScale & 7) == 0) hipLaunchKernelGGL(k_grad_hist<true>, grid, dim3(kBlockThreads), 0, st, a);
-    else hipLaunchKernelGGL(k_grad_hist<false>, grid, dim3(kBlockThreads), 0, st, a);
+    const bool raw = a.raw != nullptr && (a.N & 3) == 0;
+    if ((a.cnrScale & 7) == 0) {
+        if (raw) hipLaunchKernelGGL((k_grad_hist<true, true>), grid, dim3(kBlockThreads), 0, st, a);
+        else hipLaunchKernelGGL((k_grad_hist<true, false>), grid, dim3(kBlockThreads), 0, st, a);
+    } else {
+        if (raw) hipLaunchKernelGGL((k_grad_hist<false, true>), grid, dim3(kBlockThreads), 0, st, a);
+        else hipLaunchKernelGGL((k_grad_hist<false, false>), grid, dim3(kBlockThreads), 0, st, a);
+    }
 }
 
 void launch_grad_hist_ref(hipStream_t st, const float* img, const float* relevant, const LevelDesc& l0, uint32_t* hist, int batch) {

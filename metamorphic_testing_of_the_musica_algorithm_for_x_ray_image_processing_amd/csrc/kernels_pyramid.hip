@@ -202,6 +202,93 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_fast_pf(const float* _
     }
 }
 
+// ---- level 0 straight from the raw pixels ------------------------------------------------------
+// The reference materialises sqrt and normalized images (6 + 8 B/px of traffic) before the pyramid
+// starts. Here the level-0 kernels read the uint16 pixels (2 B/px) and apply img_sqrt.comp:15 +
+// img_normalize.comp:24 to every pixel they load — the same three IEEE operations k_normalize executes,
+// so the values are bit-identical — and the normalized image is only produced on demand.
+struct RawRow {
+    float4 m;      // 8 uint16 pixels c .. c+7 (bit pattern)
+    float hl, hr;  // pixel pairs (c-2, c-1) and (c+8, c+9) (bit pattern)
+};
+struct U16Cfg {
+    uint32_t off, off_l, off_r;  // byte offsets inside a dense uint16 row; kOob where nothing is to be read
+};
+__device__ __forceinline__ U16Cfg make_u16cfg(const LaneCfg& g) {
+    U16Cfg u;
+    u.off = g.off == kOob ? kOob : g.off >> 1;
+    u.off_l = g.off_l == kOob ? kOob : g.off_l >> 1;
+    u.off_r = g.off_r == kOob ? kOob : g.off_r >> 1;
+    return u;
+}
+__device__ __forceinline__ void load_raw_row(RawRow& r, const Buf& b, uint32_t row_off, const U16Cfg& u) {
+    r.m = bload4(b, u.off + row_off);
+    r.hl = bload1(b, u.off_l + row_off);
+    r.hr = bload1(b, u.off_r + row_off);
+}
+__device__ __forceinline__ void norm8(float d[8], float4 m, float minv, float den) {
+    const uint32_t w[4] = {__float_as_uint(m.x), __float_as_uint(m.y), __float_as_uint(m.z), __float_as_uint(m.w)};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        d[2 * k] = norm_px(w[k] & 0xFFFFu, minv, den);
+        d[2 * k + 1] = norm_px(w[k] >> 16, minv, den);
+    }
+}
+__device__ __forceinline__ void convert_row(RowR& r, const RawRow& w, const LaneCfg& g, float minv, float den) {
+    norm8(r.v, w.m, minv, den);
+    const uint32_t l = __float_as_uint(w.hl), h = __float_as_uint(w.hr);
+    // halo values only matter on lane 0 / lane 63 of strips that have a neighbour; elsewhere the loads returned 0
+    r.hl0 = norm_px(l & 0xFFFFu, minv, den);
+    r.hl1 = norm_px(l >> 16, minv, den);
+    r.hr = norm_px(h & 0xFFFFu, minv, den);
+}
+
+// K1 + K4 + K5 + K6 at level 0: the pipelined kernel above with uint16 input.
+// Algorithmic bytes: 2 * S^2 in + 4 * (S/2)^2 out = 3 bytes per input pixel.
+__global__ __launch_bounds__(kBlockThreads) void k_reduce_u16_pf(const uint16_t* __restrict__ px, float* __restrict__ out, int S,
+                                                                 int So, int opitch, size_t out_plane, int rows_per_wave,
+                                                                 const uint32_t* __restrict__ minmax, int min_chain_exact) {
+    const int lane = threadIdx.x & 63;
+    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int yo0 = seg * rows_per_wave;
+    if (yo0 >= So) return;  // wave-uniform
+    const int yo1 = min(yo0 + rows_per_wave, So);
+    const int img = blockIdx.z;
+    float minv, maxv;
+    chain_scalars(minmax, img, min_chain_exact, minv, maxv);
+    const float den = maxv - minv;
+    const Buf ib = make_buf(px + (size_t)img * S * S, (size_t)S * S * 2);
+    const Buf ob = make_buf(out + (size_t)img * out_plane, out_plane * 4);
+    const LaneCfg g = make_cfg(blockIdx.x, lane, S);
+    const U16Cfg u = make_u16cfg(g);
+    const int hi = S - 1;
+    const uint32_t rb = (uint32_t)S * 2u, orb = (uint32_t)opitch * 4u;
+    const int dir = (seg & 1) ? -1 : 1;  // see k_reduce_fast_pf
+    const int n = yo1 - yo0;
+    const int yfirst = dir > 0 ? yo0 : yo1 - 1;
+    RowR w0, w1, w2, w3, w4;
+    RawRow a, b;
+    load_raw_row(a, ib, (uint32_t)mirror_idx(2 * yfirst - 2 * dir, hi) * rb, u);
+    convert_row(w0, a, g, minv, den);
+    load_raw_row(a, ib, (uint32_t)mirror_idx(2 * yfirst - dir, hi) * rb, u);
+    convert_row(w1, a, g, minv, den);
+    load_raw_row(a, ib, (uint32_t)(2 * yfirst) * rb, u);
+    convert_row(w2, a, g, minv, den);
+    load_raw_row(a, ib, (uint32_t)mirror_idx(2 * yfirst + dir, hi) * rb, u);
+    load_raw_row(b, ib, (uint32_t)mirror_idx(2 * yfirst + 2 * dir, hi) * rb, u);
+    for (int t = 0; t < n; t++) {
+        const int yo = yfirst + dir * t;
+        convert_row(w3, a, g, minv, den);   // the pair requested one trip ago
+        convert_row(w4, b, g, minv, den);
+        const int yn = yfirst + dir * min(t + 1, n - 1);
+        load_raw_row(a, ib, (uint32_t)mirror_idx(2 * yn + dir, hi) * rb, u);
+        load_raw_row(b, ib, (uint32_t)mirror_idx(2 * yn + 2 * dir, hi) * rb, u);
+        if (dir > 0) reduce_row(w0, w1, w2, w3, w4, g, ob, (uint32_t)yo * orb);  // wave-uniform
+        else reduce_row(w4, w3, w2, w1, w0, g, ob, (uint32_t)yo * orb);
+        w0 = w2; w1 = w3; w2 = w4;
+    }
+}
+
 // Rotating-register form of the pipelined kernel: the 5-row window plus the row pair in flight
 // occupy 7 register slots and the window advances by 2 slots per output row, so after 7 rows the
 // slot assignment repeats. The loop body is unrolled over that period with compile-time slot
@@ -424,36 +511,56 @@ __device__ __forceinline__ void lowpass_pair(const CRow& a, const CRow& b, const
 
 // K7 + K8 + K9: band = fine - lowpass(coarse). rows_per_wave counts COARSE rows (2 fine rows each);
 // T coarse rows per loop trip (T + 4T 16-byte loads per lane in flight).
-template <int T>
+// U16: the fine image is the raw uint16 input (dense rows of S pixels), normalised on the fly (level 0).
+template <int T, bool U16>
 __global__ __launch_bounds__(kBlockThreads) void k_band_fast(const float* __restrict__ fine, const float* __restrict__ coarse,
                                                              float* __restrict__ band, int S, int pitch, size_t plane,
-                                                             int Sc, int cpitch, size_t cplane, int rows_per_wave) {
+                                                             int Sc, int cpitch, size_t cplane, int rows_per_wave,
+                                                             const uint32_t* __restrict__ minmax, int min_chain_exact) {
     const int lane = threadIdx.x & 63;
     const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
     const int k0 = seg * rows_per_wave;
     if (k0 >= Sc) return;
     const int k1 = min(k0 + rows_per_wave, Sc);
-    const Buf fb = make_buf(fine + (size_t)blockIdx.z * plane, plane * 4);
+    float minv = 0.0f, den = 1.0f;
+    if (U16) {
+        float maxv;
+        chain_scalars(minmax, blockIdx.z, min_chain_exact, minv, maxv);
+        den = maxv - minv;
+    }
+    const Buf fb = U16 ? make_buf(reinterpret_cast<const uint16_t*>(fine) + (size_t)blockIdx.z * S * S, (size_t)S * S * 2)
+                       : make_buf(fine + (size_t)blockIdx.z * plane, plane * 4);
     const Buf bb = make_buf(band + (size_t)blockIdx.z * plane, plane * 4);
     const Buf cb = make_buf(coarse + (size_t)blockIdx.z * cplane, cplane * 4);
     const LaneCfg g = make_cfg(blockIdx.x, lane, S);
     const uint32_t rb = (uint32_t)pitch * 4u, crb = (uint32_t)cpitch * 4u;
+    const uint32_t urb = (uint32_t)S * 2u, uoff = g.off == kOob ? kOob : g.off >> 1;
 
     CRow cw[T + 2];  // coarse rows km1(k), k .. k+T-1, kp1(k+T-1)
     load_crow(cw[0], cb, (uint32_t)coarse_of_fine(2 * k0 - 2, S) * crb, g);
     load_crow(cw[1], cb, (uint32_t)k0 * crb, g);
     for (int k = k0; k < k1; k += T) {
         float fe[T][8], fo[T][8];
+        float4 re[T], ro[T];  // raw uint16 rows (U16)
 #pragma unroll
         for (int t = 0; t < T; t++) {
             const int ka = min(k + t, k1 - 1);
             load_crow(cw[t + 2], cb, (uint32_t)coarse_of_fine(2 * ka + 2, S) * crb, g);
-            load8(fe[t], fb, g.off + (uint32_t)(2 * ka) * rb);
-            load8(fo[t], fb, g.off + (uint32_t)(2 * ka + 1) * rb);
+            if (U16) {
+                re[t] = bload4(fb, uoff + (uint32_t)(2 * ka) * urb);
+                ro[t] = bload4(fb, uoff + (uint32_t)(2 * ka + 1) * urb);
+            } else {
+                load8(fe[t], fb, g.off + (uint32_t)(2 * ka) * rb);
+                load8(fo[t], fb, g.off + (uint32_t)(2 * ka + 1) * rb);
+            }
         }
 #pragma unroll
         for (int t = 0; t < T; t++) {
             if (k + t < k1) {  // wave-uniform
+                if (U16) {
+                    norm8(fe[t], re[t], minv, den);
+                    norm8(fo[t], ro[t], minv, den);
+                }
                 float lowE[8], lowO[8];
                 lowpass_pair(cw[t], cw[t + 1], cw[t + 2], g, lowE, lowO);
 #pragma unroll
@@ -766,14 +873,30 @@ void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* 
     }
 }
 
+// Level 0 from the raw uint16 pixels (S % 8 == 0 only; the caller checks).
+void launch_reduce_u16(hipStream_t st, const uint16_t* px, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave,
+                       const uint32_t* minmax, int min_chain_exact) {
+    hipLaunchKernelGGL(k_reduce_u16_pf, stream_grid(li.S, lo.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, px, out, li.S, lo.S, lo.pitch,
+                       lo.plane, rows_per_wave, minmax, min_chain_exact);
+}
+void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
+                     int rows_per_wave, int rows_per_trip, const uint32_t* minmax, int min_chain_exact) {
+    const dim3 grid = stream_grid(lf.S, lc.S, rows_per_wave, batch);
+    const float* fine = reinterpret_cast<const float*>(px);
+    if (rows_per_trip >= 2)
+        hipLaunchKernelGGL((k_band_fast<2, true>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
+    else
+        hipLaunchKernelGGL((k_band_fast<1, true>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
+}
+
 void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc,
                  int batch, int rows_per_wave, bool force_generic, int rows_per_trip) {
     if (fast_ok(lf.S) && !force_generic) {
         const dim3 grid = stream_grid(lf.S, lc.S, rows_per_wave, batch);
         if (rows_per_trip >= 2)
-            hipLaunchKernelGGL(k_band_fast<2>, grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave);
+            hipLaunchKernelGGL((k_band_fast<2, false>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, nullptr, 0);
         else
-            hipLaunchKernelGGL(k_band_fast<1>, grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave);
+            hipLaunchKernelGGL((k_band_fast<1, false>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, nullptr, 0);
     } else {
         hipLaunchKernelGGL(k_band_generic, generic_grid(lf.S, batch), kGenericBlock, 0, st, fine, coarse, band, lf.S, lf.pitch,
                            lf.plane, lc.S, lc.pitch, lc.plane);

@@ -42,11 +42,18 @@ struct GradArgs {
     int cnrS, cnrPitch; size_t cnrPlane;
     int cnrScale;            // uint(ceil(N / float(cnrS))), img_relevant.comp:32
     int groups_per_wave;     // 16-row groups each wavefront walks
+    const uint16_t* raw;     // non-NULL: test `normalized <= 0.9` on the raw pixels (dense rows of N) instead of reading `normalized`
+    const uint32_t* minmax;
+    int min_chain_exact;
 };
 
 // kernels_pyramid.hip
 void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave, bool force_generic, int rows_per_trip, int tag);
 void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave, bool force_generic, int rows_per_trip);
+void launch_reduce_u16(hipStream_t st, const uint16_t* px, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave,
+                       const uint32_t* minmax, int min_chain_exact);
+void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
+                     int rows_per_wave, int rows_per_trip, const uint32_t* minmax, int min_chain_exact);
 void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch);
 void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic, int rows_per_trip);
 void launch_exp_band(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch);

@@ -56,6 +56,8 @@ struct musica_ctx {
     hipStream_t cur;         // stream the run_*_level helpers launch on (stream or side)
     hipStream_t side;        // coarse-level chain runs here, concurrently with the level-0 kernels on `stream`
     hipEvent_t ev_fork, ev_join;
+    bool fuse_u16;           // level-0 kernels read the raw uint16 pixels; the normalized image is produced on demand only
+    bool norm_valid;         // d_norm holds the normalized image of the current input
     bool dag;                // two-stream dispatch (MUSICA_DAG=0 falls back to one in-order stream)
     // device state
     uint16_t* d_input;
@@ -238,6 +240,8 @@ musica_ctx* musica_create(const musica_params* params) {
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     c->dag = env_int("MUSICA_DAG", 1) != 0;
+    c->fuse_u16 = env_int("MUSICA_U16", 1) != 0 && (N % 8) == 0 && !(params->flags & MUSICA_FLAG_GENERIC_KERNELS);
+    c->norm_valid = false;
     ok = ok && dalloc(c, &c->d_input, B * N * N);
     ok = ok && dalloc(c, &c->d_minmax, B * kMinMaxStride);
     ok = ok && dalloc(c, &c->d_norm, B * c->lv[0].plane);
@@ -331,13 +335,32 @@ static const float* level_input(musica_ctx* c, int i) { return i == 0 ? c->d_nor
 // stage "norm" (src/vk_processing.cpp:2182-2222)
 static void enqueue_norm(musica_ctx* c) {
     { Span sp(c, MUSICA_KERNEL_MINMAX); launch_minmax(c->stream, c->cur_input, c->N, c->d_minmax, c->B); }
-    { Span sp(c, MUSICA_KERNEL_NORMALIZE); launch_normalize(c->stream, c->cur_input, c->d_norm, c->lv[0], c->d_minmax, c->min_chain_exact, c->B); }
+    c->norm_valid = false;
+    if (!c->fuse_u16 || c->d_clahe_hist) {  // the CLAHE block reads the stored normalized image through k_relevant
+        Span sp(c, MUSICA_KERNEL_NORMALIZE);
+        launch_normalize(c->stream, c->cur_input, c->d_norm, c->lv[0], c->d_minmax, c->min_chain_exact, c->B);
+        c->norm_valid = true;
+    }
+}
+// The normalized image for getters / dumps when the hot path skipped it.
+static void ensure_normalized(musica_ctx* c) {
+    if (c->norm_valid) return;
+    launch_normalize(c->stream, c->cur_input, c->d_norm, c->lv[0], c->d_minmax, c->min_chain_exact, c->B);
+    c->norm_valid = true;
 }
 
 static void run_reduce_level(musica_ctx* c, int i, int rows) {
+    if (i == 0 && c->fuse_u16) {
+        launch_reduce_u16(c->cur, c->cur_input, c->lv[0], c->d_down[0], c->lv[1], c->B, rows, c->d_minmax, c->min_chain_exact);
+        return;
+    }
     launch_reduce(c->cur, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, rows, c->generic, c->reduce_trip, c->tuning ? 3 : (i == 0 ? 0 : 1));
 }
 static void run_band_level(musica_ctx* c, int i, int rows) {
+    if (i == 0 && c->fuse_u16) {
+        launch_band_u16(c->cur, c->cur_input, c->d_down[0], c->d_band[0], c->lv[0], c->lv[1], c->B, rows, c->band_trip, c->d_minmax, c->min_chain_exact);
+        return;
+    }
     launch_band(c->cur, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, rows, c->generic, c->band_trip);
 }
 static void run_sdev_level(musica_ctx* c, int i, int rows) {
@@ -425,6 +448,9 @@ static void enqueue_gradation(musica_ctx* c) {
         g.N = l0.S; g.pitch = l0.pitch; g.plane = l0.plane;
         g.cnrS = l3.S; g.cnrPitch = l3.pitch; g.cnrPlane = l3.plane; g.cnrScale = scale;
         g.groups_per_wave = c->grad_groups;
+        g.raw = c->fuse_u16 ? c->cur_input : nullptr;
+        g.minmax = c->d_minmax;
+        g.min_chain_exact = c->min_chain_exact;
         launch_grad_hist(c->stream, g, c->B);
     }
     { Span sp(c, MUSICA_KERNEL_GRAD_CURVE); launch_grad_curve(c->stream, c->d_grad_hist, c->d_grad_max, c->d_gcurve, c->B); }
@@ -674,7 +700,7 @@ static int resolve_image(musica_ctx* c, uint32_t idx, musica_image_kind kind, ui
     const LevelDesc& l0 = c->lv[0];
     const LevelDesc& l3 = c->lv[MUSICA_CNR_LEVEL];
     switch (kind) {
-        case MUSICA_IMG_NORMALIZED: *plane = c->d_norm + idx * l0.plane; *desc = &c->lv[0]; return 1;
+        case MUSICA_IMG_NORMALIZED: ensure_normalized(c); *plane = c->d_norm + idx * l0.plane; *desc = &c->lv[0]; return 1;
         case MUSICA_IMG_GRADED: *plane = c->d_graded + idx * l0.plane; *desc = &c->lv[0]; return 1;
         case MUSICA_IMG_CLAHE_GRADED:
             if (!c->d_clahe_graded) return fail("musica_get_image: ctx was created without MUSICA_FLAG_CLAHE");
@@ -690,6 +716,7 @@ static int resolve_image(musica_ctx* c, uint32_t idx, musica_image_kind kind, ui
             HIP_OK(hipMemsetAsync(c->d_scratch, 0, c->lv[level].plane * sizeof(float), c->stream));
             *plane = c->d_scratch; return 1;
         case MUSICA_IMG_RELEVANT:
+            ensure_normalized(c);
             launch_relevant(c->stream, c->d_norm, c->d_cnr, c->d_scratch, l0, l3, (int)cnr_scale(l0.S, l3.S), c->B);
             *plane = c->d_scratch + idx * l0.plane; *desc = &c->lv[0]; return 1;
         case MUSICA_IMG_SQRT:
@@ -721,7 +748,9 @@ int musica_debug_set_image(musica_ctx* c, uint32_t idx, musica_image_kind kind, 
     if (!src) return fail("musica_debug_set_image: src is NULL");
     if (musica_image_side(c, kind, level) == 0) return fail("musica_debug_set_image: no image kind=%d level=%u", (int)kind, level);
     switch (kind) {
-        case MUSICA_IMG_NORMALIZED: return upload_plane(c, c->d_norm + idx * c->lv[0].plane, c->lv[0], src);
+        case MUSICA_IMG_NORMALIZED:
+            if (c->fuse_u16) return fail("musica_debug_set_image: the normalized image is not stored on the hot path (level 0 reads the raw pixels)");
+            return upload_plane(c, c->d_norm + idx * c->lv[0].plane, c->lv[0], src);
         case MUSICA_IMG_GRADED: return upload_plane(c, c->d_graded + idx * c->lv[0].plane, c->lv[0], src);
         case MUSICA_IMG_CNR: return upload_plane(c, c->d_cnr + idx * c->lv[MUSICA_CNR_LEVEL].plane, c->lv[MUSICA_CNR_LEVEL], src);
         case MUSICA_IMG_DOWNSAMPLED: return upload_plane(c, c->d_down[level] + idx * c->lv[level + 1].plane, c->lv[level + 1], src);
