@@ -76,7 +76,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed steps")
+    ap.add_argument("--kernel-events", action="store_true",
+                    help="bracket the metric kernel with HIP events inside the timed steps (forces eager launches: stream "
+                         "capture drops event records, so the default timed region replays the hipGraph without events)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel event passes after the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,9 +128,12 @@ def main():
         step()
     proc.sync()
 
-    # HIP events on the library's stream around the metric kernel only (2 records per step);
-    # bracketing all ~33 launches costs ~18 % of the step, so the full table comes from a second pass
-    kernel_events = not args.no_kernel_events
+    # The timed region replays the captured hipGraph (the product's default dispatch). ROCm 7.2 stream capture
+    # drops hipEventRecord calls (devtools/graph_events.hip), so HIP events around a kernel need eager launches:
+    # the metric kernel is bracketed in a second pass over the same K steps right after the timed region
+    # (2 records per step), and all ~33 launches in a third pass (costs ~18 % of the step) for the "kernels" table.
+    # --kernel-events moves the metric-kernel events into the timed region itself (eager launches, ~4 % slower).
+    kernel_events = args.kernel_events
     proc.profile_reset()
     proc.profile_enable(["reduce_l0"] if kernel_events else False)
 
@@ -153,16 +159,26 @@ def main():
         elapsed = float(tt.item())
     proc.profile_enable(False)
     prof_timed = proc.profile()
-    # second, untimed pass over the same steps with every kernel family bracketed -> "kernels" table
-    proc.profile_reset()
-    proc.profile_enable(True)
-    for _ in range(args.steps):
-        step()
-    proc.sync()
-    proc.profile_enable(False)
-    prof = proc.profile()
-    if kernel_events and prof_timed["reduce_l0"][1]:
-        prof["reduce_l0"] = prof_timed["reduce_l0"]              # the live measurement of the timed region wins
+    prof = {}
+    if not args.no_kernel_events:
+        if not kernel_events:
+            proc.profile_reset()
+            proc.profile_enable(["reduce_l0"])
+            for _ in range(args.steps):
+                step()
+            proc.sync()
+            proc.profile_enable(False)
+            prof_timed = proc.profile()
+        # untimed pass over the same steps with every kernel family bracketed -> "kernels" table
+        proc.profile_reset()
+        proc.profile_enable(True)
+        for _ in range(args.steps):
+            step()
+        proc.sync()
+        proc.profile_enable(False)
+        prof = proc.profile()
+    if prof_timed.get("reduce_l0", (0, 0))[1]:
+        prof["reduce_l0"] = prof_timed["reduce_l0"]              # the metric-kernel-only measurement wins
 
     result = None
     if rank == 0:
@@ -239,7 +255,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "image_size": n, "levels": levels, "images_per_gpu_per_step": batch,
-                       "input": "seeded phantoms, %d-bit" % bits, "kernel_events_in_timed_region": kernel_events,
+                       "input": "seeded phantoms, %d-bit" % bits, "dispatch": "eager launches" if (kernel_events or os.environ.get("MUSICA_GRAPH", "1") == "0") else "hipGraph replay",
+                       "kernel_events_in_timed_region": kernel_events,
                        "stats_gathered": int(st.shape[0])},
             "roofline": roofline, "roofline_4096": roofline_4096, "cpu_baseline": cpu, "kernels": kernels,
             "e2e_host_MPps": round(e2e, 1),

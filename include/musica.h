@@ -274,6 +274,14 @@ int musica_k_reduce(musica_ctx* ctx, const float* d_in, uint32_t side, uint32_t 
 int musica_k_reduce_timed(musica_ctx* ctx, const float* d_in, uint32_t side, uint32_t in_pitch,
                           float* d_out, uint32_t out_pitch, uint32_t batch, uint32_t iters, double* mean_us);
 
+/* Self-test of the exact arithmetic shortcuts that lean on a hardware approximation (v_rsq_f32) and therefore
+ * cannot be checked on a CPU (csrc/exact_math.h): runs on the ctx device over EVERY float bit pattern and counts
+ * disagreements with the literal expressions of the shaders (img_sqrt.comp:15, img_sdev.comp:30,
+ * img_normalize.comp:24). mismatches[0]: musica_sqrt vs sqrtf, 2^32 patterns; [1]: the 8-wide grouped form;
+ * [2]: the grouped form with a +0 among the eight; [3]: the normalisation of a raw pixel for every
+ * (pixel, min, max) triple the chains can produce (65536 x 256 x 256). All four must be 0. */
+int musica_selftest_exact_math(musica_ctx* ctx, uint64_t mismatches[4]);
+
 /* Raw device memory helpers so callers without a HIP binding (ctypes tests,
  * bench.py) can stage buffers for the two functions above. */
 void* musica_device_alloc(musica_ctx* ctx, size_t bytes);

@@ -47,3 +47,58 @@ MUSICA_HD int musica_noise_bin(float cur) {
     if (safe) return (int)fl;        // cur == 0 gives t1 = 0.5 -> bin 0 == break; NaN fails every comparison
     return musica_noise_bin_exact(cur);
 }
+
+// img_normalize.comp:24, `(sqrt - min) / (max - min)`: both chain scalars are integer-valued floats in
+// 0 .. 255 (kernels_common.h chain_scalars), so den = max - min is an integer 1 .. 255 (0: flat image, the
+// caller keeps the literal division for it) and x = sqrtf(v) - min for a 16-bit v. With rden = RN(1 / den)
+// (one literal division per image) the quotient is q0 = x * rden corrected once through the exact FMA
+// residual. Equal to x / den for EVERY (v, min, den) triple of that domain — 65536 x 256 x 255 cases, all
+// checked by oracle/exhaustive.c musica_check_norm_div (tests/test_exact_math.py).
+MUSICA_HD float musica_norm_div(float x, float den, float rden) {
+    const float q = x * rden;
+    const float r = fmaf(-den, q, x);
+    return fmaf(r, rden, q);
+}
+
+#if defined(__HIPCC__)
+// sqrtf(x) from one v_rsq_f32 and one FMA residual step: y = rsq(x), s = x * y, s' = s + (x - s * s) * (y / 2).
+// On gfx950 this equals the correctly rounded sqrtf for EVERY float in [2^-100, FLT_MAX] and for +0 (rsq(0) = inf
+// is clamped so that s = 0); below 2^-100 the residual underflows, and +inf / NaN / negatives go wrong — those
+// take the literal sqrtf. v_rsq_f32 is a hardware approximation, so the exhaustive check runs on the GPU itself:
+// musica_selftest_sqrt (tests/test_gpu_parity.py) compares both functions below with sqrtf over all 2^32 patterns.
+__device__ __forceinline__ float musica_sqrt_core(float x) {
+    const float y = fminf(__builtin_amdgcn_rsqf(x), 3.0e38f);
+    const float s = x * y, h = 0.5f * y;
+    const float r = fmaf(-s, s, x);
+    return fmaf(r, h, s);
+}
+// True when musica_sqrt_core(x) is proven exact: x == +0 or 2^-100 <= x <= FLT_MAX.
+__device__ __forceinline__ bool musica_sqrt_core_ok(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return u == 0u || (u - 0x0D800000u) < (0x7F800000u - 0x0D800000u);
+}
+// Eight at once with one range test for the group: every bit pattern below +inf (this also rejects NaN, -0 and
+// negatives, whose patterns are larger) and every non-zero one at least 2^-100 (pattern - 1 wraps for +0).
+__device__ __forceinline__ void musica_sqrt8(float s[8]) {
+    uint32_t mx = 0u, mn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t u = __float_as_uint(s[j]);
+        mx = max(mx, u);
+        mn = min(mn, u - 1u);
+    }
+    const bool ok = mx < 0x7F800000u && mn >= 0x0D800000u - 1u;
+    if (__builtin_expect(ok, 1)) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = musica_sqrt_core(s[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = sqrtf(s[j]);
+    }
+}
+__device__ __forceinline__ float musica_sqrt(float x) {
+    const float s = musica_sqrt_core(x);
+    if (__builtin_expect(!musica_sqrt_core_ok(x), 0)) return sqrtf(x);
+    return s;
+}
+#endif

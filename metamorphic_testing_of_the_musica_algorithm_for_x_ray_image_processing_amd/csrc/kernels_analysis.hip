@@ -81,6 +81,44 @@ __global__ __launch_bounds__(256) void k_minmax_u16(const uint16_t* __restrict__
     }
 }
 
+// ---- self-test of exact_math.h on the device (musica_selftest_exact_math) ----------------
+__device__ __forceinline__ bool same_float(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
+__global__ __launch_bounds__(256) void k_selftest_sqrt(unsigned long long* __restrict__ bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long b0 = 0, b1 = 0, b2 = 0;
+    for (uint64_t grp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; grp < (1ull << 29); grp += stride) {
+        float want[8], s[8], z[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float x = __uint_as_float((uint32_t)(grp * 8 + j));
+            want[j] = sqrtf(x);
+            s[j] = x;
+            z[j] = j == (int)(grp & 7) ? 0.0f : x;
+            if (!same_float(musica_sqrt(x), want[j])) b0++;
+        }
+        musica_sqrt8(s);
+        musica_sqrt8(z);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (!same_float(s[j], want[j])) b1++;
+            if (!same_float(z[j], j == (int)(grp & 7) ? 0.0f : want[j])) b2++;
+        }
+    }
+    if (b0) atomicAdd(&bad[0], b0);
+    if (b1) atomicAdd(&bad[1], b1);
+    if (b2) atomicAdd(&bad[2], b2);
+}
+// blockIdx.x = min, blockIdx.y = max (both as the chains deliver them: integer-valued floats 0 .. 255)
+__global__ __launch_bounds__(256) void k_selftest_norm(unsigned long long* __restrict__ bad) {
+    if (blockIdx.y < blockIdx.x) return;
+    const float minv = (float)blockIdx.x, maxv = (float)blockIdx.y;
+    const NormK nk = make_norm(minv, maxv);
+    unsigned long long b = 0;
+    for (uint32_t v = threadIdx.x; v < 65536u; v += blockDim.x)
+        if (!same_float(norm_px(v, nk), norm_px(v, minv, maxv - minv))) b++;
+    if (b) atomicAdd(&bad[3], b);
+}
+
 // ---- K1 + K4 --------------------------------------------------------------------------
 // out = (sqrt(float(px)) - min) / (max - min), unclamped (img_normalize.comp:24-27).
 // Vector path: 8 pixels per thread when N % 8 == 0 (dense u16 rows and pitched f32 rows both 16-byte aligned).
@@ -89,7 +127,7 @@ __global__ __launch_bounds__(256) void k_normalize(const uint16_t* __restrict__ 
     const int img = blockIdx.z;
     float minv, maxv;
     chain_scalars(minmax, img, min_chain_exact, minv, maxv);
-    const float den = maxv - minv;
+    const NormK nk = make_norm(minv, maxv);
     const uint16_t* p = px + (size_t)img * N * N;
     float* o = out + (size_t)img * plane;
     if ((N & 7) == 0 && ((uintptr_t)p & 15u) == 0) {
@@ -102,8 +140,8 @@ __global__ __launch_bounds__(256) void k_normalize(const uint16_t* __restrict__ 
             float r[8];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                r[2 * k] = (sqrtf((float)(w[k] & 0xFFFFu)) - minv) / den;
-                r[2 * k + 1] = (sqrtf((float)(w[k] >> 16)) - minv) / den;
+                r[2 * k] = norm_px(w[k] & 0xFFFFu, nk);
+                r[2 * k + 1] = norm_px(w[k] >> 16, nk);
             }
             float* d = o + (size_t)y * pitch + xv * 8;
             *reinterpret_cast<float4*>(d) = make_float4(r[0], r[1], r[2], r[3]);
@@ -113,7 +151,7 @@ __global__ __launch_bounds__(256) void k_normalize(const uint16_t* __restrict__ 
         const size_t total = (size_t)N * N;
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
             const int y = (int)(i / N), x = (int)(i % N);
-            o[(size_t)y * pitch + x] = (sqrtf((float)p[i]) - minv) / den;
+            o[(size_t)y * pitch + x] = norm_px((uint32_t)p[i], nk);
         }
     }
 }
@@ -230,7 +268,8 @@ __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const S
     s[6] = sum5(q[4], q[5], q[6], q[7], b0);
     s[7] = sum5(q[5], q[6], q[7], b0, b1);
 #pragma unroll
-    for (int j = 0; j < 8; j++) s[j] = sqrtf(musica_div25(s[j]));  // img_sdev.comp:30 (exact x / 25, exact_math.h)
+    for (int j = 0; j < 8; j++) s[j] = musica_div25(s[j]);  // img_sdev.comp:30 (exact x / 25, exact_math.h)
+    musica_sqrt8(s);                                         // img_sdev.comp:30 (exact sqrt, exact_math.h)
     if (g.valid == 8) {
         *reinterpret_cast<float4*>(drow + g.c) = make_float4(s[0], s[1], s[2], s[3]);
         *reinterpret_cast<float4*>(drow + g.c + 4) = make_float4(s[4], s[5], s[6], s[7]);
@@ -599,6 +638,11 @@ void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& 
                 int batch) {
     hipLaunchKernelGGL(k_cnr, dim3((l3.S + 31) / 32, (l3.S + 7) / 8, batch), dim3(32, 8), 0, st, sdev, cnr, l3.S, l3.pitch, l3.plane,
                        maxpts, levels);
+}
+
+void launch_selftest_exact_math(hipStream_t st, unsigned long long* d_bad4) {
+    hipLaunchKernelGGL(k_selftest_sqrt, dim3(8192), dim3(256), 0, st, d_bad4);
+    hipLaunchKernelGGL(k_selftest_norm, dim3(256, 256), dim3(256), 0, st, d_bad4);
 }
 
 void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact,

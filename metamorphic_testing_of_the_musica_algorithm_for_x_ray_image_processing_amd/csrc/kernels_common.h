@@ -2,6 +2,7 @@
 #pragma once
 
 #include "musica_device.h"
+#include "exact_math.h"
 
 namespace musica {
 
@@ -112,8 +113,30 @@ __device__ __forceinline__ void chain_scalars(const uint32_t* __restrict__ minma
     maxv = (float)f2u(sqrtf((float)mxu));
     minv = min_chain_exact ? (float)f2u(sqrtf((float)mnu)) : 0.0f;
 }
-// img_sqrt.comp:15 + img_normalize.comp:24 for one raw pixel (den = max - min).
+// img_sqrt.comp:15 + img_normalize.comp:24 for one raw pixel (den = max - min), literally.
 __device__ __forceinline__ float norm_px(uint32_t v, float minv, float den) { return (sqrtf((float)v) - minv) / den; }
+// The same value from the exact shortcuts of exact_math.h: 9 + 1 + 4 VALU slots instead of 18 + 1 + 14.
+// Both chain scalars are integers 0 .. 255, so den is an integer 0 .. 255: den >= 1 is the exhaustively checked
+// domain of musica_norm_div; den == 0 (flat image) gives x / 0 = x * inf, which is q itself (rden = 1 / 0 = inf).
+struct NormK {
+    float minv, den, rden;
+    bool flat;
+};
+__device__ __forceinline__ NormK make_norm(float minv, float maxv) {
+    NormK k;
+    k.minv = minv;
+    k.den = maxv - minv;
+    k.rden = 1.0f / k.den;
+    k.flat = !(k.den >= 1.0f);
+    return k;
+}
+__device__ __forceinline__ float norm_px(uint32_t v, const NormK& k) {
+    const float x = musica_sqrt_core((float)v) - k.minv;  // v <= 65535: inside the core's exact range
+    const float q = x * k.rden;
+    const float r = fmaf(-k.den, q, x);
+    const float f = fmaf(r, k.rden, q);
+    return k.flat ? q : f;
+}
 // Largest raw value whose normalized value is <= 0.90 (img_relevant.comp:56), -1 if there is none. norm_px is
 // non-decreasing in v (sqrt, subtraction and division by den >= 0 are monotone; den == 0 gives inf / NaN, for
 // which the comparison is false for every v), so `normalized <= 0.9` is exactly `raw <= threshold`.

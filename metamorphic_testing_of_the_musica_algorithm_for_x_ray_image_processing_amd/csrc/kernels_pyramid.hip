@@ -226,21 +226,21 @@ __device__ __forceinline__ void load_raw_row(RawRow& r, const Buf& b, uint32_t r
     r.hl = bload1(b, u.off_l + row_off);
     r.hr = bload1(b, u.off_r + row_off);
 }
-__device__ __forceinline__ void norm8(float d[8], float4 m, float minv, float den) {
+__device__ __forceinline__ void norm8(float d[8], float4 m, const NormK& nk) {
     const uint32_t w[4] = {__float_as_uint(m.x), __float_as_uint(m.y), __float_as_uint(m.z), __float_as_uint(m.w)};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        d[2 * k] = norm_px(w[k] & 0xFFFFu, minv, den);
-        d[2 * k + 1] = norm_px(w[k] >> 16, minv, den);
+        d[2 * k] = norm_px(w[k] & 0xFFFFu, nk);
+        d[2 * k + 1] = norm_px(w[k] >> 16, nk);
     }
 }
-__device__ __forceinline__ void convert_row(RowR& r, const RawRow& w, const LaneCfg& g, float minv, float den) {
-    norm8(r.v, w.m, minv, den);
+__device__ __forceinline__ void convert_row(RowR& r, const RawRow& w, const LaneCfg& g, const NormK& nk) {
+    norm8(r.v, w.m, nk);
     const uint32_t l = __float_as_uint(w.hl), h = __float_as_uint(w.hr);
     // halo values only matter on lane 0 / lane 63 of strips that have a neighbour; elsewhere the loads returned 0
-    r.hl0 = norm_px(l & 0xFFFFu, minv, den);
-    r.hl1 = norm_px(l >> 16, minv, den);
-    r.hr = norm_px(h & 0xFFFFu, minv, den);
+    r.hl0 = norm_px(l & 0xFFFFu, nk);
+    r.hl1 = norm_px(l >> 16, nk);
+    r.hr = norm_px(h & 0xFFFFu, nk);
 }
 
 // K1 + K4 + K5 + K6 at level 0: the pipelined kernel above with uint16 input.
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_u16_pf(const uint16_t*
     const int img = blockIdx.z;
     float minv, maxv;
     chain_scalars(minmax, img, min_chain_exact, minv, maxv);
-    const float den = maxv - minv;
+    const NormK nk = make_norm(minv, maxv);
     const Buf ib = make_buf(px + (size_t)img * S * S, (size_t)S * S * 2);
     const Buf ob = make_buf(out + (size_t)img * out_plane, out_plane * 4);
     const LaneCfg g = make_cfg(blockIdx.x, lane, S);
@@ -269,17 +269,17 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_u16_pf(const uint16_t*
     RowR w0, w1, w2, w3, w4;
     RawRow a, b;
     load_raw_row(a, ib, (uint32_t)mirror_idx(2 * yfirst - 2 * dir, hi) * rb, u);
-    convert_row(w0, a, g, minv, den);
+    convert_row(w0, a, g, nk);
     load_raw_row(a, ib, (uint32_t)mirror_idx(2 * yfirst - dir, hi) * rb, u);
-    convert_row(w1, a, g, minv, den);
+    convert_row(w1, a, g, nk);
     load_raw_row(a, ib, (uint32_t)(2 * yfirst) * rb, u);
-    convert_row(w2, a, g, minv, den);
+    convert_row(w2, a, g, nk);
     load_raw_row(a, ib, (uint32_t)mirror_idx(2 * yfirst + dir, hi) * rb, u);
     load_raw_row(b, ib, (uint32_t)mirror_idx(2 * yfirst + 2 * dir, hi) * rb, u);
     for (int t = 0; t < n; t++) {
         const int yo = yfirst + dir * t;
-        convert_row(w3, a, g, minv, den);   // the pair requested one trip ago
-        convert_row(w4, b, g, minv, den);
+        convert_row(w3, a, g, nk);   // the pair requested one trip ago
+        convert_row(w4, b, g, nk);
         const int yn = yfirst + dir * min(t + 1, n - 1);
         load_raw_row(a, ib, (uint32_t)mirror_idx(2 * yn + dir, hi) * rb, u);
         load_raw_row(b, ib, (uint32_t)mirror_idx(2 * yn + 2 * dir, hi) * rb, u);
@@ -522,11 +522,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_band_fast(const float* __rest
     const int k0 = seg * rows_per_wave;
     if (k0 >= Sc) return;
     const int k1 = min(k0 + rows_per_wave, Sc);
-    float minv = 0.0f, den = 1.0f;
+    NormK nk = make_norm(0.0f, 1.0f);
     if (U16) {
-        float maxv;
+        float minv, maxv;
         chain_scalars(minmax, blockIdx.z, min_chain_exact, minv, maxv);
-        den = maxv - minv;
+        nk = make_norm(minv, maxv);
     }
     const Buf fb = U16 ? make_buf(reinterpret_cast<const uint16_t*>(fine) + (size_t)blockIdx.z * S * S, (size_t)S * S * 2)
                        : make_buf(fine + (size_t)blockIdx.z * plane, plane * 4);
@@ -558,8 +558,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_band_fast(const float* __rest
         for (int t = 0; t < T; t++) {
             if (k + t < k1) {  // wave-uniform
                 if (U16) {
-                    norm8(fe[t], re[t], minv, den);
-                    norm8(fo[t], ro[t], minv, den);
+                    norm8(fe[t], re[t], nk);
+                    norm8(fo[t], ro[t], nk);
                 }
                 float lowE[8], lowO[8];
                 lowpass_pair(cw[t], cw[t + 1], cw[t + 2], g, lowE, lowO);

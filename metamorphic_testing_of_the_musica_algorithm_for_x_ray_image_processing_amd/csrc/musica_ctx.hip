@@ -58,6 +58,11 @@ struct musica_ctx {
     hipEvent_t ev_fork, ev_join;
     bool fuse_u16;           // level-0 kernels read the raw uint16 pixels; the normalized image is produced on demand only
     bool norm_valid;         // d_norm holds the normalized image of the current input
+    // hipGraph replay of the two-stream dispatch (captured once per input pointer; MUSICA_FLAG_NO_GRAPH /
+    // MUSICA_GRAPH=0 / per-kernel profiling fall back to eager launches)
+    bool use_graph;
+    hipGraphExec_t graph_exec;
+    const uint16_t* graph_input;
     bool dag;                // two-stream dispatch (MUSICA_DAG=0 falls back to one in-order stream)
     // device state
     uint16_t* d_input;
@@ -175,6 +180,7 @@ void musica_destroy(musica_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (void* p : c->allocations) hipFree(p);
+    if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -240,6 +246,9 @@ musica_ctx* musica_create(const musica_params* params) {
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     c->dag = env_int("MUSICA_DAG", 1) != 0;
+    c->use_graph = c->dag && !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", 1) != 0;
+    c->graph_exec = nullptr;
+    c->graph_input = nullptr;
     c->fuse_u16 = env_int("MUSICA_U16", 1) != 0 && (N % 8) == 0 && !(params->flags & MUSICA_FLAG_GENERIC_KERNELS);
     c->norm_valid = false;
     ok = ok && dalloc(c, &c->d_input, B * N * N);
@@ -507,7 +516,32 @@ static void enqueue_dag(musica_ctx* c) {
     enqueue_gradation(c);
 }
 
+// Captures enqueue_dag() (both streams: the side stream joins the capture through ev_fork and rejoins
+// through ev_join) into an executable graph for the current input pointer.
+static bool capture_graph(musica_ctx* c) {
+    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
+    enqueue_dag(c);
+    if (hipStreamEndCapture(c->stream, &graph) != hipSuccess || !graph) { (void)hipGetLastError(); return false; }
+    const hipError_t e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) { c->graph_exec = nullptr; (void)hipGetLastError(); return false; }
+    c->graph_input = c->cur_input;
+    return true;
+}
+
 static int enqueue_all(musica_ctx* c) {
+    if (c->dag && !c->tuning && c->use_graph && c->profiling == 0) {
+        if (!c->graph_exec || c->graph_input != c->cur_input) {
+            if (!capture_graph(c)) c->use_graph = false;   // e.g. a runtime without capture support: stay eager
+        }
+        if (c->graph_exec && c->graph_input == c->cur_input) {
+            c->norm_valid = c->d_clahe_hist != nullptr || !c->fuse_u16;
+            if (hipGraphLaunch(c->graph_exec, c->stream) != hipSuccess) return fail("hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError()));
+            return 1;
+        }
+    }
     if (c->dag && !c->tuning) {
         enqueue_dag(c);
         hipError_t e0 = hipGetLastError();
@@ -1002,6 +1036,24 @@ int musica_k_reduce(musica_ctx* c, const float* d_in, uint32_t side, uint32_t in
     launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, pick_rows(c->reduce_rows, 1, li.S, lo.S, (int)batch), c->generic, c->reduce_trip, 2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e));
+    return 1;
+}
+
+int musica_selftest_exact_math(musica_ctx* c, uint64_t mismatches[4]) {
+    CHECK_CTX(c);
+    if (!mismatches) return fail("musica_selftest_exact_math: mismatches is NULL");
+    unsigned long long* d = nullptr;
+    HIP_OK(hipMalloc(&d, 4 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) {
+        launch_selftest_exact_math(c->stream, d);
+        e = hipStreamSynchronize(c->stream);
+    }
+    unsigned long long h[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return fail("musica_selftest_exact_math: %s", hipGetErrorString(e));
+    for (int i = 0; i < 4; i++) mismatches[i] = h[i];
     return 1;
 }
 

@@ -128,6 +128,7 @@ ABI = {
     "musica_profile_reset": (C.c_int, [_VP]),
     "musica_profile_get": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "musica_k_reduce": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32]),
+    "musica_selftest_exact_math": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "musica_k_reduce_timed": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     "musica_device_alloc": (_VP, [_VP, C.c_size_t]),
     "musica_device_free": (None, [_VP, _VP]),
@@ -410,6 +411,12 @@ class MusicaProcessing:
             self.device_free(d_in)
             self.device_free(d_out)
         return out[:, :, :so].copy()
+
+    def selftest_exact_math(self):
+        """Mismatch counts of the device-side exact shortcuts over every float bit pattern (all must be 0)."""
+        out = (C.c_uint64 * 4)()
+        self._ok(self._lib.musica_selftest_exact_math(self._h, out), "musica_selftest_exact_math")
+        return list(out)
 
     def k_reduce_timed(self, side, batch=1, iters=50, seed=0):
         """Mean microseconds per launch of the metric kernel on a random side x side image in HBM."""

@@ -33,3 +33,23 @@ long musica_check_noise_bin(uint32_t lo_bits, uint32_t hi_bits, uint32_t* first_
     if (first_bad) *first_bad = first;
     return bad;
 }
+
+/* musica_norm_div over its whole domain: v in 0..65535, min in [min_lo, min_hi) (integers 0..255), den in 1..255
+ * with min + den <= 255 ... and, beyond what chain_scalars can produce, every den 1..255 for every min. */
+long musica_check_norm_div(int min_lo, int min_hi, uint32_t* first_bad) {
+    long bad = 0;
+    uint32_t first = 0xFFFFFFFFu;
+#pragma omp parallel for reduction(+ : bad) reduction(min : first) schedule(dynamic, 1) collapse(2)
+    for (int m = min_lo; m < min_hi; m++) {
+        for (int d = 1; d <= 255; d++) {
+            const float minv = (float)m, den = (float)d, rden = 1.0f / den;
+            for (uint32_t v = 0; v < 65536u; v++) {
+                const float x = sqrtf((float)v) - minv;
+                const float a = musica_norm_div(x, den, rden), b = x / den;
+                if (!(a == b)) { bad++; const uint32_t code = ((uint32_t)m << 24) | ((uint32_t)d << 16) | v; if (code < first) first = code; }
+            }
+        }
+    }
+    if (first_bad) *first_bad = first;
+    return bad;
+}

@@ -17,6 +17,8 @@ def ex(ob):
         fn = getattr(lib, name)
         fn.restype = C.c_long
         fn.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.musica_check_norm_div.restype = C.c_long
+    lib.musica_check_norm_div.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     return lib
 
 
@@ -32,3 +34,11 @@ def test_noise_bin_is_exact_for_every_nonnegative_float(ex):
     assert bad == 0, "first mismatch at bits 0x%08x" % first.value
     bad = ex.musica_check_noise_bin(0x7F800001, 0x7FFFFFFF, C.byref(first))   # NaNs: both say "break"
     assert bad == 0
+
+
+def test_norm_div_is_exact_on_its_whole_domain(ex):
+    """(sqrtf(v) - min) / den through one reciprocal multiply + FMA residual step == the IEEE division for every
+    16-bit v, every integer min 0..255 and every integer den 1..255 (4.3e9 cases, a few seconds)."""
+    first = C.c_uint32()
+    bad = ex.musica_check_norm_div(0, 256, C.byref(first))
+    assert bad == 0, "first mismatch (min << 24 | den << 16 | v) = 0x%08x" % first.value
