@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--batch", type=int, default=0, help="override the workload's images per GPU per step (experiments only)")
     ap.add_argument("--kernel-events", action="store_true",
                     help="bracket the metric kernel with HIP events inside the timed steps (forces eager launches: stream "
                          "capture drops event records, so the default timed region replays the hipGraph without events)")
@@ -104,6 +105,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n, levels, batch, bits, flags, desc = WORKLOADS[args.workload]
+    if args.batch > 0:
+        batch = args.batch
+        desc += " [--batch %d override]" % batch
     seeds = [100 + rank * batch + k for k in range(batch)]          # C4 uses default_rng(100 + k)
     px = np.stack([phantom(n, s, bits=bits) for s in seeds])
 

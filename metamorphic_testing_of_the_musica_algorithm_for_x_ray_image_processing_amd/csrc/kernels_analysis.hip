@@ -47,21 +47,33 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
     return v;
 }
 
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void minmax_acc(us2& mn, us2& mx, const uint4& q) {   // v_pk_min_u16 / v_pk_max_u16: two pixels per slot
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const us2 v = __builtin_bit_cast(us2, w[k]);
+        mn = __builtin_elementwise_min(mn, v);
+        mx = __builtin_elementwise_max(mx, v);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_minmax_u16(const uint16_t* __restrict__ px, size_t count, uint32_t* __restrict__ minmax) {
     const uint16_t* p = px + (size_t)blockIdx.z * count;
-    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
     const size_t nvec = (((uintptr_t)p & 15u) == 0) ? count / 8 : 0;  // 8 pixels per 16-byte load
     const uint4* pv = reinterpret_cast<const uint4*>(p);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
-        const uint4 q = pv[i];
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t lo = w[k] & 0xFFFFu, hi = w[k] >> 16;
-            mn = min(mn, min(lo, hi));
-            mx = max(mx, max(lo, hi));
-        }
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    us2 mn2 = {0xFFFFu, 0xFFFFu}, mx2 = {0u, 0u};
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {   // four independent 16-byte loads in flight per lane
+        const uint4 q0 = pv[i], q1 = pv[i + stride], q2 = pv[i + 2 * stride], q3 = pv[i + 3 * stride];
+        minmax_acc(mn2, mx2, q0);
+        minmax_acc(mn2, mx2, q1);
+        minmax_acc(mn2, mx2, q2);
+        minmax_acc(mn2, mx2, q3);
     }
+    for (; i < nvec; i += stride) minmax_acc(mn2, mx2, pv[i]);
+    uint32_t mn = min((uint32_t)mn2.x, (uint32_t)mn2.y), mx = max((uint32_t)mx2.x, (uint32_t)mx2.y);
     for (size_t i = nvec * 8 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t v = p[i];
         mn = min(mn, v);

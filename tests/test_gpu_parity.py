@@ -132,6 +132,41 @@ def test_resident_input_entry_point(ob):
     p.cleanup()
 
 
+@pytest.mark.parametrize("flags", [0, mp.FLAG_CLAHE, mp.FLAG_NO_GRAPH])
+def test_image_groups_give_the_same_bits(ob, flags, monkeypatch):
+    """The batch cut into concurrently running groups (uneven: 5 images -> 2 + 2 + 1) equals the single-group
+    run bit for bit, every getter addresses the right image, and per-kernel profiling still counts every launch."""
+    n, levels, b = 520, 5, 5
+    px = np.stack([phantom(n, 500 + k) for k in range(b)])
+    monkeypatch.setenv("MUSICA_GROUPS", "1")
+    one = _proc(n, levels, batch=b, flags=flags)
+    monkeypatch.setenv("MUSICA_GROUPS", "3")
+    grp = _proc(n, levels, batch=b, flags=flags)
+    for rep in range(2):
+        assert one.execute(px) and grp.execute(px)
+        _same(one.graded(), grp.graded(), "graded (groups vs one)")
+    for k in (0, 2, 4):
+        o = ob.Oracle(n, levels, ob.ORDER_FAST, flags & 1).execute(px[k])
+        _compare_all(grp, o, ob, idx=k, tag="group image %d: " % k)
+        if flags & mp.FLAG_CLAHE:
+            _same(grp.image(mp.IMG_CLAHE_GRADED, 0, k), o.image(ob.IMG_CLAHE_GRADED), "clahe graded %d" % k)
+    grp.profile_enable(True)
+    assert grp.execute(px)
+    grp.profile_enable(False)
+    prof = grp.profile()
+    assert prof["reduce_l0"][1] == 3 and prof["grad_apply"][1] == 3      # one launch per group
+    _same(one.graded(), grp.graded(), "graded (groups, profiling)")
+    d = grp.device_alloc(px.nbytes)
+    grp.h2d(d, px[::-1].copy())
+    assert grp.execute_device(d)
+    grp.sync()
+    assert one.execute(px[::-1].copy())
+    _same(one.graded(), grp.graded(), "graded (groups, caller-owned input)")
+    grp.device_free(d)
+    one.cleanup()
+    grp.cleanup()
+
+
 def test_exact_math_shortcuts_on_the_device():
     """csrc/exact_math.h: the rsq-based sqrt (single and 8-wide grouped, +0 mixed in) against sqrtf over all
     2^32 float patterns, and the shortcut normalisation against the literal one over every (pixel, min, max)."""
