@@ -259,7 +259,7 @@ __device__ __forceinline__ float sum5(float a, float b, float c, float d, float 
 // One output row of sdev from its five rows of squares + the histogram scan of that row.
 template <bool HIST>
 __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const SRow& r2, const SRow& r3, const SRow& r4, const SCfg& g, int S,
-                                         int y, int cov, float* __restrict__ drow, uint32_t* lh, uint32_t& alive) {
+                                         int y, int cov, float* __restrict__ drow, uint32_t* lh, bool (&alive)[8]) {
     float q[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) q[j] = sum5(r0.q[j], r1.q[j], r2.q[j], r3.q[j], r4.q[j]);
@@ -290,19 +290,19 @@ __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const S
         for (int j = 0; j < 8; j++)
             if (j < g.valid) drow[g.c + j] = s[j];
     }
-    // noise_hist.comp:20-47 — branch-free: a dead or breaking column adds 0 to a per-lane scratch word
-    if ((y & (kHistArea - 1)) == 0) alive = 0xFFu;
+    // noise_hist.comp:20-47, branch-free. A run adds until its first `break` (bin 0): alive[j] afterwards is exactly
+    // "this texel is counted". A dead column adds into the lane's scratch word; bin 2048 (out of the histogram
+    // image, dropped by Q1 without breaking) is lane 0's scratch word, so it needs no test of its own. Columns
+    // outside the image / the dispatch coverage start every run dead (their texel would read 0 -> break).
     if (HIST && y < cov) {
         const int lane = threadIdx.x & 63;
+        const bool rearm = (y & (kHistArea - 1)) == 0;   // wave-uniform
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const int x = g.c + j;
-            const float cur = (j < g.valid && x < cov) ? s[j] : 0.0f;
-            const int bin = musica_noise_bin(cur);                           // 0 = break (:29, :33, :39); exact (exact_math.h)
-            const bool live = (alive >> j) & 1u;
-            if (bin == 0) alive &= ~(1u << j);
-            const bool add = live && bin > 0 && bin < MUSICA_NOISE_BINS;    // bin 2048 is dropped (Q1) but does not break
-            atomicAdd(&lh[add ? bin : MUSICA_NOISE_BINS + lane], add ? 1u : 0u);  // :45
+            const int bin = musica_noise_bin(s[j]);                           // 0 = break (:29, :33, :39); exact (exact_math.h)
+            const bool start = j < g.valid && g.c + j < cov;
+            alive[j] = (rearm ? start : alive[j]) && bin != 0;
+            atomicAdd(&lh[alive[j] ? bin : MUSICA_NOISE_BINS + lane], 1u);    // :45
         }
     }
 }
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist(const float* __rest
         load_srow(w[1], bb, roff(y0 - 1), g, S);
         load_srow(w[2], bb, roff(y0), g, S);
         load_srow(w[3], bb, roff(y0 + 1), g, S);
-        uint32_t alive = 0;
+        bool alive[8] = {false, false, false, false, false, false, false, false};
         for (int y = y0; y < y1; y += T) {
 #pragma unroll
             for (int t = 0; t < T; t++) load_srow(w[t + 4], bb, roff(y + t + 2), g, S);
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __r
         load_srow(w2, bb, roff(y0), g, S);
         load_srow(w3, bb, roff(y0 + 1), g, S);
         load_sraw(raw, bb, roff(y0 + 2), g);
-        uint32_t alive = 0;
+        bool alive[8] = {false, false, false, false, false, false, false, false};
         for (int y = y0; y < y1; y++) {
             square_srow(w4, raw, g, S);
             load_sraw(raw, bb, roff(y + 3), g);  // rows past the image carry an out-of-range offset: no access
@@ -632,6 +632,7 @@ void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const Leve
     if (dbg == 1) hipLaunchKernelGGL((k_sdev_hist<4, false>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
     else if (dbg == 2) hipLaunchKernelGGL((k_sdev_hist<1, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
     else if (dbg == 3) hipLaunchKernelGGL((k_sdev_hist<2, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
+    else if (dbg == 5) hipLaunchKernelGGL((k_sdev_hist_pf<false>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
     else if (dbg == 4) hipLaunchKernelGGL((k_sdev_hist<4, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
     else hipLaunchKernelGGL((k_sdev_hist_pf<true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
 }

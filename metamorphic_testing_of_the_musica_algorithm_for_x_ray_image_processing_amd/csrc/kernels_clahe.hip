@@ -13,7 +13,9 @@ namespace musica {
 constexpr int kT = MUSICA_CLAHE_TILES;
 constexpr int kB = MUSICA_CLAHE_BINS;
 
-// K22 clahe_histogram.comp:13-45 — hist[tx][ty][bin] += 1 where relevant == 1.0
+// K22 clahe_histogram.comp:13-45 — hist[tx][ty][bin] += 1 where relevant == 1.0.
+// One workgroup per band of 8 consecutive rows (a band touches one or two tile rows, so its flush is short; the
+// LDS copy still holds all 16 tiles), 4 columns per thread with 16-byte loads.
 __global__ __launch_bounds__(256) void k_clahe_hist(const float* __restrict__ img, const float* __restrict__ relevant, int N, int pitch,
                                                     size_t plane, uint32_t* __restrict__ hist) {
     __shared__ uint32_t lh[kT * kT * kB];
@@ -21,18 +23,27 @@ __global__ __launch_bounds__(256) void k_clahe_hist(const float* __restrict__ im
     __syncthreads();
     img += (size_t)blockIdx.z * plane;
     relevant += (size_t)blockIdx.z * plane;
-    const size_t total = (size_t)N * N;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int y = (int)(i / N), x = (int)(i % N);
-        const float cur = img[(size_t)y * pitch + x];
-        if (cur != cur) continue;
-        const float scaled = cur * (float)(kB - 1) + 0.5f;                       // :20
-        if (!(scaled > -2147483648.0f && scaled < 2147483648.0f)) continue;
-        const int bin = (int)scaled;
-        const uint32_t tx = f2u((float)x / (float)N * (float)kT);               // :34
-        const uint32_t ty = f2u((float)y / (float)N * (float)kT);               // :35
-        if (relevant[(size_t)y * pitch + x] == 1.0f && bin >= 0 && bin < kB && tx < (uint32_t)kT && ty < (uint32_t)kT)
-            atomicAdd(&lh[(tx * kT + ty) * kB + bin], 1u);                       // :39-44
+    const float fN = (float)N;
+    for (int y = blockIdx.x * 8; y < min(blockIdx.x * 8 + 8, N); y++) {
+        const uint32_t ty = f2u((float)y / fN * (float)kT);                      // :35
+        const float* irow = img + (size_t)y * pitch;
+        const float* rrow = relevant + (size_t)y * pitch;
+        for (int x0 = threadIdx.x * 4; x0 < N; x0 += blockDim.x * 4) {
+            const float4 c4 = load4_guard(irow, x0, N), r4 = load4_guard(rrow, x0, N);
+            const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                const float cur = cv[j];
+                const float scaled = cur * (float)(kB - 1) + 0.5f;               // :20
+                // NaN never indexes (Q6); int(scaled) must land in [0, 256): scaled in (-1, 256)
+                const bool inrange = scaled > -1.0f && scaled < (float)kB;
+                const int bin = inrange ? (int)scaled : 0;
+                const uint32_t tx = f2u((float)x / fN * (float)kT);             // :34
+                if (x < N && inrange && rv[j] == 1.0f && tx < (uint32_t)kT && ty < (uint32_t)kT)
+                    atomicAdd(&lh[(tx * kT + ty) * kB + bin], 1u);               // :39-44
+            }
+        }
     }
     __syncthreads();
     uint32_t* gh = hist + (size_t)blockIdx.z * kT * kT * kB;
@@ -42,47 +53,65 @@ __global__ __launch_bounds__(256) void k_clahe_hist(const float* __restrict__ im
     }
 }
 
-// K23 clahe_grad_curve.comp:21-100 — one thread per tile (local_size 4x4, one workgroup).
-__global__ void k_clahe_curve(const uint32_t* __restrict__ hist, musica_point* __restrict__ points) {
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const uint32_t* h = hist + ((size_t)blockIdx.x * kT * kT + (size_t)tx * kT + ty) * kB;
-    musica_point* pts = points + ((size_t)blockIdx.x * kT * kT + (size_t)tx * kT + ty) * kB;
-    uint32_t count = 0;
-    for (int i = 0; i < kB; i++) count += h[i];                                  // :31-43
+// K23 clahe_grad_curve.comp:21-100 — the reference runs one thread per tile; here one 256-thread workgroup per
+// tile stages the histogram and the per-bin quotients in LDS, and thread 0 performs the two float accumulations
+// (clip excess, running sum) in the shader's index order, so the sums round exactly as the serial loops do.
+__global__ __launch_bounds__(kB) void k_clahe_curve(const uint32_t* __restrict__ hist, musica_point* __restrict__ points) {
+    __shared__ float ny[kB];
+    __shared__ uint32_t part[kB];
+    __shared__ float s_clipAdd;
+    const int tile = blockIdx.x, i = threadIdx.x;                                // tile = tx * kT + ty
+    const uint32_t* h = hist + ((size_t)blockIdx.y * kT * kT + tile) * kB;
+    musica_point* pts = points + ((size_t)blockIdx.y * kT * kT + tile) * kB;
+    const uint32_t hv = h[i];
+    part[i] = hv;
+    __syncthreads();
+    for (int st = kB / 2; st >= 1; st >>= 1) {                                   // :31-43 (uint sum: any order)
+        if (i < st) part[i] += part[i + st];
+        __syncthreads();
+    }
+    const uint32_t count = part[0];
     const float clipLimit = 1.0f / 32.0f;                                        // :60
-    float clipCount = 0.0f;
-    for (int i = 0; i < kB; i++) {                                               // :47-57, :63-69
-        const float ny = (float)h[i] / (float)count;
-        if (ny > clipLimit) clipCount += ny - clipLimit;
+    const float q = (float)hv / (float)count;
+    ny[i] = q;
+    __syncthreads();
+    if (i == 0) {
+        float clipCount = 0.0f;
+        for (int k = 0; k < kB; k++)                                             // :47-57, :63-69
+            if (ny[k] > clipLimit) clipCount += ny[k] - clipLimit;
+        s_clipAdd = clipCount / (float)kB;                                       // :76
     }
-    const float clipAdd = clipCount / (float)kB;                                 // :76
-    float curr = 0.0f;
-    for (int i = 0; i < kB; i++) {                                               // :78-93
-        float ny = (float)h[i] / (float)count;
-        if (ny > clipLimit) ny = clipLimit;
-        ny += clipAdd;
-        curr += ny;
-        float posX = (float)i * (1.0f / (float)kB);
-        if (i == kB - 1) posX = 1.0f;
-        pts[i].x = posX;
-        pts[i].y = curr;
+    __syncthreads();
+    float v = q;
+    if (v > clipLimit) v = clipLimit;                                            // :78-93
+    v += s_clipAdd;
+    __syncthreads();
+    ny[i] = v;
+    __syncthreads();
+    if (i == 0) {
+        float curr = 0.0f;
+        for (int k = 0; k < kB; k++) { curr += ny[k]; ny[k] = curr; }
     }
+    __syncthreads();
+    pts[i].x = i == kB - 1 ? 1.0f : (float)i * (1.0f / (float)kB);
+    pts[i].y = ny[i];
 }
 
-// getY() of clahe_grad_curve_apply.comp:27-36 on one tile's 256 points. x[i] = i/256 (x[255] = 1) is
-// strictly increasing, so the first match is i = j - 1 with j = #{x[i] < s} (same argument as curve_eval).
+// getY() of clahe_grad_curve_apply.comp:27-36 on one tile's 256 points. The abscissae are x[i] = i/256 for
+// i < 255 and x[255] = 1: strictly increasing, so the first match is i = j - 1 with j = #{x[i] < s} (same
+// argument as curve_eval), and j has a closed form: i/256 < s <=> i < 256 s (exact: power-of-two scaling)
+// <=> i <= ceil(256 s) - 1, capped at the 255 regular abscissae, plus one if 1 < s. NaN compares false: j = 0.
+// The slope divides by x[j] - x[j-1] = 1/256 (2/256 for the last segment): multiplying by 256 (128) is the
+// same correctly rounded value.
 __device__ __forceinline__ float clahe_x(int i) { return i == kB - 1 ? 1.0f : (float)i * (1.0f / (float)kB); }
 __device__ __forceinline__ float clahe_get_y(const musica_point* __restrict__ pts, float s) {
     int j = 0;
-#pragma unroll
-    for (int step = 256; step >= 1; step >>= 1) {
-        const int probe = j + step;
-        if (probe <= kB && clahe_x(probe - 1) < s) j = probe;
-    }
+    if (s > 0.0f) j = (int)fminf(ceilf(s * (float)kB), (float)(kB - 1));
+    if (s > 1.0f) j += 1;
     if (j == 0) return (s == 0.0f) ? pts[0].y : 0.0f;
     if (j >= kB) return 0.0f;
-    const float y0 = pts[j - 1].y, y1 = pts[j].y, x0 = clahe_x(j - 1), x1 = clahe_x(j);
-    const float m = (y1 - y0) / (x1 - x0);
+    const float y0 = pts[j - 1].y, y1 = pts[j].y, x0 = clahe_x(j - 1);
+    const float m = (y1 - y0) * (j == kB - 1 ? (float)(kB / 2) : (float)kB);
     return m * (s - x0) + y0;
 }
 
@@ -133,8 +162,8 @@ __global__ void k_clahe_apply(const float* __restrict__ in, float* __restrict__ 
 
 void launch_clahe(hipStream_t st, const float* img, const float* relevant, float* out, const LevelDesc& l0, uint32_t* hist, musica_point* pts,
                   int batch) {
-    hipLaunchKernelGGL(k_clahe_hist, dim3(256, 1, batch), dim3(256), 0, st, img, relevant, l0.S, l0.pitch, l0.plane, hist);
-    hipLaunchKernelGGL(k_clahe_curve, dim3(batch), dim3(kT, kT), 0, st, hist, pts);
+    hipLaunchKernelGGL(k_clahe_hist, dim3((l0.S + 7) / 8, 1, batch), dim3(256), 0, st, img, relevant, l0.S, l0.pitch, l0.plane, hist);
+    hipLaunchKernelGGL(k_clahe_curve, dim3(kT * kT, batch), dim3(kB), 0, st, hist, pts);
     hipLaunchKernelGGL(k_clahe_apply, dim3((l0.S + 31) / 32, (l0.S + 7) / 8, batch), dim3(32, 8), 0, st, img, out, l0.S, l0.pitch, l0.plane, pts);
 }
 

@@ -238,9 +238,12 @@ __device__ __forceinline__ void convert_row(RowR& r, const RawRow& w, const Lane
     norm8(r.v, w.m, nk);
     const uint32_t l = __float_as_uint(w.hl), h = __float_as_uint(w.hr);
     // halo values only matter on lane 0 / lane 63 of strips that have a neighbour; elsewhere the loads returned 0
-    r.hl0 = norm_px(l & 0xFFFFu, nk);
+    // (lane 0 uses hl0 / hl1, lane 63 uses hr: one conversion serves both ends, and with hr == hl0 the
+    // vertical chains of reduce_row over hr and hl0 are the same expression)
+    const float ends = norm_px(g.lane63 ? (h & 0xFFFFu) : (l & 0xFFFFu), nk);
+    r.hl0 = ends;
     r.hl1 = norm_px(l >> 16, nk);
-    r.hr = norm_px(h & 0xFFFFu, nk);
+    r.hr = ends;
 }
 
 // K1 + K4 + K5 + K6 at level 0: the pipelined kernel above with uint16 input.
