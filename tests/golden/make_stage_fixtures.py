@@ -1,0 +1,78 @@
+"""Generates tests/golden/stages_*.npz and stage_digests.json: the oracle's (MUSICA_ORDER_FAST) output at every
+stage for small seeded phantoms (full arrays) and, for the BASELINE-sized cases, SHA-256 digests of the same
+arrays. The reference ships no golden vectors for this path, so these are regression pins of the
+build's own oracle ("parity unpinned" still holds): they catch drift of the oracle between rounds, compiler /
+libm differences between the build container and the GPU box's CPU, and they give the HIP path a committed target.
+
+Run from the repo root:  python tests/golden/make_stage_fixtures.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import binding as ob  # noqa: E402
+from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.phantom import phantom  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FULL = [(64, 4, 41, 0), (96, 5, 42, 0), (136, 0, 43, 1)]              # (N, levels, seed, flags): stored as arrays
+DIGEST = [(512, 4, 1, 0), (520, 5, 44, 0), (1024, 6, 7, 0), (512, 5, 45, 1)]   # stored as digests
+
+
+def stages(o, clahe):
+    """Every stage output of one executed oracle, as {name: array}."""
+    out = {"normalized": o.image(ob.IMG_NORMALIZED), "minmax": np.array(o.minmax(), dtype=np.float32)}
+    for i in range(o.levels):
+        out["downsampled_%d" % i] = o.image(ob.IMG_DOWNSAMPLED, i)
+        out["bandpass_%d" % i] = o.image(ob.IMG_BANDPASS, i)
+        out["expand_%d" % i] = o.image(ob.IMG_EXPAND, i)
+        out["contrast_curve_%d" % i] = o.contrast_curve(i)
+    for i in range(4):
+        out["sdev_%d" % i] = o.image(ob.IMG_SDEV, i)
+        out["noise_hist_%d" % i] = o.noise_hist(i)
+        out["noise_hist_max_%d" % i] = np.array(o.noise_hist_max(i), dtype=np.uint32)
+    out["cnr"] = o.image(ob.IMG_CNR, 3)
+    out["grad_hist"] = o.grad_hist()
+    out["grad_hist_max"] = np.array(o.grad_hist_max(), dtype=np.uint32)
+    gc, gw = o.grad_curve()
+    out["grad_curve"] = gc
+    out["grad_window"] = np.array(gw, dtype=np.float32)
+    out["graded"] = o.image(ob.IMG_GRADED)
+    out["out_pixels"] = o.out_pixels()
+    if clahe:
+        out["clahe_hist"] = o.clahe_hist()
+        out["clahe_curves"] = o.clahe_curves()
+        out["clahe_graded"] = o.image(ob.IMG_CLAHE_GRADED)
+    return out
+
+
+def digest(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype.kind == "f":   # one bit pattern per value: -0 -> +0, every NaN -> the default NaN
+        a = np.where(np.isnan(a), np.float32(np.nan), a + np.float32(0.0)).astype(a.dtype)
+    return hashlib.sha256(a.tobytes()).hexdigest()[:32]
+
+
+def run(n, levels, seed, flags):
+    o = ob.Oracle(n, levels, ob.ORDER_FAST, flags)
+    o.execute(phantom(n, seed))
+    return stages(o, flags & 1)
+
+
+def main():
+    for n, levels, seed, flags in FULL:
+        st = run(n, levels, seed, flags)
+        np.savez_compressed(os.path.join(HERE, "stages_%d_L%d_s%d_f%d.npz" % (n, levels, seed, flags)), **st)
+    dig = {}
+    for n, levels, seed, flags in DIGEST:
+        st = run(n, levels, seed, flags)
+        dig["%d_L%d_s%d_f%d" % (n, levels, seed, flags)] = {k: digest(v) for k, v in st.items()}
+    json.dump(dig, open(os.path.join(HERE, "stage_digests.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
