@@ -12,6 +12,7 @@
 #include "kernels_common.h"
 #include "exact_math.h"
 #include "launchers.h"
+#include "sdev_parts.h"
 
 namespace musica {
 
@@ -178,135 +179,7 @@ __global__ void k_sqrt(const uint16_t* __restrict__ px, float* __restrict__ out,
     }
 }
 
-// ---- K10 + K11 ------------------------------------------------------------------------
-// sdev(x, y) = sqrt( sum_{5x5} band^2 / 25 ), taps outside the image are 0 and the divisor stays 25
-// (img_sdev.comp:14-30). ORDER_FAST: vertical chain of squares, then horizontal chain.
-// The noise histogram (noise_hist.comp) is accumulated on the fly: the reference's thread (gx, gy)
-// walks its 16x16 area column by column (m = x outer, n = y inner) and `break`s out of a column at
-// the first pixel that is 0, > 0.1 or lands in bin 0 — i.e. each (column, 16-row run) is an
-// independent early-exit scan. A lane of this kernel owns 8 columns and marches down rows, so it
-// sees every run in exactly that order: one `alive` bit per owned column, re-armed every 16 rows.
-// Bins are privatised in LDS (8 KiB per block) and flushed with one global atomic per non-empty bin.
-struct SRow {
-    float q[8];    // squares of columns c .. c+7
-    float l0, l1;  // squares of columns c-2, c-1   (lane 0 of a strip that is not the first)
-    float h0, h1;  // squares of columns c+8, c+9   (lane 63)
-};
-
-// Byte offsets of one lane inside a row; kOob where the access would leave the image (reads as 0: Q1).
-struct SCfg {
-    int c;
-    uint32_t off0, off1;  // 16-byte groups c .. c+3, c+4 .. c+7
-    uint32_t off_l;       // c-2, c-1 (lane 0)
-    uint32_t off_r;       // c+8, c+9 (lane 63)
-    int valid;            // number of in-image columns among the lane's 8 (pad columns of a pitched row must read as 0)
-    bool lane0, lane63;
-};
-
-__device__ __forceinline__ SCfg make_scfg(int strip, int lane, int S) {
-    SCfg g;
-    g.c = strip * kStripCols + lane * kLaneCols;
-    g.lane0 = lane == 0;
-    g.lane63 = lane == 63;
-    g.valid = min(max(S - g.c, 0), 8);
-    g.off0 = g.c < S ? (uint32_t)g.c * 4u : kOob;
-    g.off1 = g.c + 4 < S ? (uint32_t)(g.c + 4) * 4u : kOob;
-    g.off_l = (g.lane0 && g.c >= 2 && g.c < S) ? (uint32_t)(g.c - 2) * 4u : kOob;
-    g.off_r = (g.lane63 && g.c + 8 < S) ? (uint32_t)(g.c + 8) * 4u : kOob;
-    return g;
-}
-
-// row_off = kOob for rows outside the image. Columns >= S inside the last 16-byte group and the odd
-// right-halo column are masked to 0 by `valid` / the c+9 test when the row is squared.
-struct SRaw {
-    float4 a, d;
-    float2 l, h;
-};
-__device__ __forceinline__ void load_sraw(SRaw& r, const Buf& b, uint32_t row_off, const SCfg& g) {
-    // kOob has only bit 31 set and every in-image offset is < 2^31, so an OR keeps "either one out of range" out of range
-    r.a = bload4(b, (g.off0 + row_off) | ((g.off0 | row_off) & kOob));
-    r.d = bload4(b, (g.off1 + row_off) | ((g.off1 | row_off) & kOob));
-    r.l = bload2(b, (g.off_l + row_off) | ((g.off_l | row_off) & kOob));
-    r.h = bload2(b, (g.off_r + row_off) | ((g.off_r | row_off) & kOob));
-}
-__device__ __forceinline__ void square_srow(SRow& r, const SRaw& w, const SCfg& g, int S) {
-    const float v[8] = {w.a.x, w.a.y, w.a.z, w.a.w, w.d.x, w.d.y, w.d.z, w.d.w};
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const float t = j < g.valid ? v[j] : 0.0f;
-        r.q[j] = t * t;
-    }
-    r.l0 = w.l.x * w.l.x; r.l1 = w.l.y * w.l.y;
-    r.h0 = w.h.x * w.h.x;
-    const float h1 = (g.c + 9 < S) ? w.h.y : 0.0f;
-    r.h1 = h1 * h1;
-}
-__device__ __forceinline__ void load_srow(SRow& r, const Buf& b, uint32_t row_off, const SCfg& g, int S) {
-    SRaw w;
-    load_sraw(w, b, row_off, g);
-    square_srow(r, w, g, S);
-}
-
-__device__ __forceinline__ float sum5(float a, float b, float c, float d, float e) {
-    float acc = a;
-    acc = acc + b;
-    acc = acc + c;
-    acc = acc + d;
-    acc = acc + e;
-    return acc;
-}
-
-// One output row of sdev from its five rows of squares + the histogram scan of that row.
-template <bool HIST>
-__device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const SRow& r2, const SRow& r3, const SRow& r4, const SCfg& g, int S,
-                                         int y, int cov, float* __restrict__ drow, uint32_t* lh, bool (&alive)[8]) {
-    float q[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) q[j] = sum5(r0.q[j], r1.q[j], r2.q[j], r3.q[j], r4.q[j]);
-    const float ql0 = sum5(r0.l0, r1.l0, r2.l0, r3.l0, r4.l0), ql1 = sum5(r0.l1, r1.l1, r2.l1, r3.l1, r4.l1);
-    const float qh0 = sum5(r0.h0, r1.h0, r2.h0, r3.h0, r4.h0), qh1 = sum5(r0.h1, r1.h1, r2.h1, r3.h1, r4.h1);
-    float a6 = from_left_lane(q[6]), a7 = from_left_lane(q[7]);
-    float b0 = from_right_lane(q[0]), b1 = from_right_lane(q[1]);
-    if (g.lane0) { a6 = ql0; a7 = ql1; }    // zeros at the image's left edge (loads out of range)
-    if (g.lane63) { b0 = qh0; b1 = qh1; }   // zeros beyond the right edge
-    // lanes right of the image hold q == 0, so the last in-image lane reads zeros from its neighbour
-    float s[8];
-    s[0] = sum5(a6, a7, q[0], q[1], q[2]);
-    s[1] = sum5(a7, q[0], q[1], q[2], q[3]);
-    s[2] = sum5(q[0], q[1], q[2], q[3], q[4]);
-    s[3] = sum5(q[1], q[2], q[3], q[4], q[5]);
-    s[4] = sum5(q[2], q[3], q[4], q[5], q[6]);
-    s[5] = sum5(q[3], q[4], q[5], q[6], q[7]);
-    s[6] = sum5(q[4], q[5], q[6], q[7], b0);
-    s[7] = sum5(q[5], q[6], q[7], b0, b1);
-#pragma unroll
-    for (int j = 0; j < 8; j++) s[j] = musica_div25(s[j]);  // img_sdev.comp:30 (exact x / 25, exact_math.h)
-    musica_sqrt8(s);                                         // img_sdev.comp:30 (exact sqrt, exact_math.h)
-    if (g.valid == 8) {
-        *reinterpret_cast<float4*>(drow + g.c) = make_float4(s[0], s[1], s[2], s[3]);
-        *reinterpret_cast<float4*>(drow + g.c + 4) = make_float4(s[4], s[5], s[6], s[7]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (j < g.valid) drow[g.c + j] = s[j];
-    }
-    // noise_hist.comp:20-47, branch-free. A run adds until its first `break` (bin 0): alive[j] afterwards is exactly
-    // "this texel is counted". A dead column adds into the lane's scratch word; bin 2048 (out of the histogram
-    // image, dropped by Q1 without breaking) is lane 0's scratch word, so it needs no test of its own. Columns
-    // outside the image / the dispatch coverage start every run dead (their texel would read 0 -> break).
-    if (HIST && y < cov) {
-        const int lane = threadIdx.x & 63;
-        const bool rearm = (y & (kHistArea - 1)) == 0;   // wave-uniform
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int bin = musica_noise_bin(s[j]);                           // 0 = break (:29, :33, :39); exact (exact_math.h)
-            const bool start = j < g.valid && g.c + j < cov;
-            alive[j] = (rearm ? start : alive[j]) && bin != 0;
-            atomicAdd(&lh[alive[j] ? bin : MUSICA_NOISE_BINS + lane], 1u);    // :45
-        }
-    }
-}
-
+// ---- K10 + K11: row pieces in sdev_parts.h ------------------------------------------------
 // rows_per_wave must be a multiple of 16 (histogram runs start at y % 16 == 0) and of T.
 // cov = (imageSize / 512) * 512: the part of the grid the reference's dispatch covers (src/vk_processing.cpp:2293-2295).
 // T rows per loop trip: the T new rows are loaded back to back before any arithmetic.

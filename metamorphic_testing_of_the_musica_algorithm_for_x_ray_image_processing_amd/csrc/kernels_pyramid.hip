@@ -22,6 +22,7 @@
 // Both forms evaluate exactly the oracle's MUSICA_ORDER_FAST arithmetic.
 #include "kernels_common.h"
 #include "launchers.h"
+#include "sdev_parts.h"
 
 namespace musica {
 
@@ -579,6 +580,175 @@ __global__ __launch_bounds__(kBlockThreads) void k_band_fast(const float* __rest
     }
 }
 
+// ======================================================================================
+// K7 + K8 + K9 (+ K1 + K4 at level 0) + K10 + K11 in one march: band = fine - lowpass(coarse) is squared
+// while it is still in registers, so the 5x5 RMS and the noise histogram never re-read the band image
+// (-4 B per pixel and one launch less per level). A wavefront owns 512 columns x rows_per_wave coarse rows
+// (2 fine rows each; a multiple of 8 so that its fine rows start a 16-row histogram area) and additionally
+// computes — without storing it — the band of one row pair above and one below its segment and of two
+// columns left and right of its strip (on lane 0 / lane 63), which the 5x5 window of its own texels needs.
+// Every value is produced by the same expressions as in k_band_fast and k_sdev_hist_pf.
+// ======================================================================================
+struct CRowX {
+    CRow r;      // r.hl / r.hr hold the SAME value `near`: coarse column j0-1 on lane 0, j0+4 on lane 63
+    float far;   // coarse column j0-2 on lane 0, j0+5 on lane 63
+};
+struct XCfg {
+    uint32_t coff_x;   // byte offset of the coarse halo pair (j0-2, j0-1) on lane 0, (j0+4, j0+5) on lane 63, else kOob
+    uint32_t foff_x;   // byte offset (f32 rows) of the fine halo pair (c-2, c-1) on lane 0, (c+8, c+9) on lane 63, else kOob
+    bool edge_ok;      // this lane is lane 0 / lane 63 of a strip with a neighbour on that side
+};
+__device__ __forceinline__ XCfg make_xcfg(const LaneCfg& g) {
+    XCfg x;
+    const bool l = g.off_l != kOob, r = g.off_r != kOob;   // lane 0 with a left neighbour / lane 63 with a right one
+    x.edge_ok = l || r;
+    x.foff_x = l ? g.off_l : (r ? g.off_r : kOob);
+    x.coff_x = l ? g.coff_l - 4u : (r ? g.coff_r : kOob);
+    return x;
+}
+__device__ __forceinline__ void load_crowx(CRowX& w, const Buf& b, uint32_t row_off, const LaneCfg& g, const XCfg& x) {
+    const float4 a = bload4(b, g.coff + row_off);
+    w.r.v[0] = a.x; w.r.v[1] = a.y; w.r.v[2] = a.z; w.r.v[3] = a.w;
+    const float2 h = bload2(b, x.coff_x + row_off);
+    const float near = g.lane63 ? h.x : h.y;
+    w.r.hl = near; w.r.hr = near;
+    w.far = g.lane63 ? h.y : h.x;
+}
+// lowpass of the row pair for the lane's 8 columns (as lowpass_pair) and for its two halo columns:
+// A = the even one (c-2 or c+8), B = the odd one (c-1 or c+9).
+__device__ __forceinline__ void lowpass_pair_x(const CRowX& a, const CRowX& b, const CRowX& c, const LaneCfg& g,
+                                               float lowE[8], float lowO[8], float& lowEA, float& lowEB, float& lowOA, float& lowOB) {
+    float Ve[4], Vo[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        Ve[j] = chain_even(a.r.v[j], b.r.v[j], c.r.v[j]);
+        Vo[j] = chain_odd(b.r.v[j], c.r.v[j]);
+    }
+    const float Qe = chain_even(a.r.hl, b.r.hl, c.r.hl), Qo = chain_odd(b.r.hl, c.r.hl);   // near halo column
+    const float Fe = chain_even(a.far, b.far, c.far), Fo = chain_odd(b.far, c.far);          // far halo column
+    float l, r;
+    exchange(Ve, Qe, Qe, g, l, r);
+    hpass8(Ve, l, r, lowE);
+    exchange(Vo, Qo, Qo, g, l, r);
+    hpass8(Vo, l, r, lowO);
+    // lane 0: (P, Q, R) = (V[j0-2], V[j0-1], V[j0]); lane 63: (V[j0+3], V[j0+4], V[j0+5])
+    const float Pe = g.lane63 ? Ve[3] : Fe, Re = g.lane63 ? Fe : Ve[0];
+    const float Po = g.lane63 ? Vo[3] : Fo, Ro = g.lane63 ? Fo : Vo[0];
+    lowEA = 4.0f * chain_even(Pe, Qe, Re);
+    lowEB = 4.0f * chain_odd(Qe, Re);
+    lowOA = 4.0f * chain_even(Po, Qo, Ro);
+    lowOB = 4.0f * chain_odd(Qo, Ro);
+}
+__device__ __forceinline__ void square_band_row(SRow& r, const float b[8], float bA, float bB, const SCfg& sg, bool edge_ok) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float t = j < sg.valid ? b[j] : 0.0f;
+        r.q[j] = t * t;
+    }
+    const float a = edge_ok ? bA : 0.0f, c = edge_ok ? bB : 0.0f;   // out of the image reads 0 (Q1)
+    r.l0 = a * a; r.l1 = c * c;
+    r.h0 = r.l0; r.h1 = r.l1;
+}
+__device__ __forceinline__ void zero_srow(SRow& r) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.q[j] = 0.0f;
+    r.l0 = r.l1 = r.h0 = r.h1 = 0.0f;
+}
+
+template <bool U16>
+__global__ __launch_bounds__(kBlockThreads) void k_band_sdev_fast(const float* __restrict__ fine, const float* __restrict__ coarse,
+                                                                  float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
+                                                                  size_t plane, int Sc, int cpitch, size_t cplane, int rows_per_wave,
+                                                                  const uint32_t* __restrict__ minmax, int min_chain_exact,
+                                                                  uint32_t* __restrict__ hist, size_t hist_stride, int cov) {
+    __shared__ uint32_t lh[MUSICA_NOISE_BINS + 64];
+    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS + 64; i += blockDim.x) lh[i] = 0u;
+    __syncthreads();
+    const int img = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int k0 = seg * rows_per_wave;
+    if (k0 < Sc) {
+        const int k1 = min(k0 + rows_per_wave, Sc);
+        NormK nk = make_norm(0.0f, 1.0f);
+        if (U16) {
+            float minv, maxv;
+            chain_scalars(minmax, img, min_chain_exact, minv, maxv);
+            nk = make_norm(minv, maxv);
+        }
+        const Buf fb = U16 ? make_buf(reinterpret_cast<const uint16_t*>(fine) + (size_t)img * S * S, (size_t)S * S * 2)
+                           : make_buf(fine + (size_t)img * plane, plane * 4);
+        const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
+        const Buf cb = make_buf(coarse + (size_t)img * cplane, cplane * 4);
+        float* srow0 = sdev + (size_t)img * plane;
+        const LaneCfg g = make_cfg(blockIdx.x, lane, S);
+        const SCfg sg = make_scfg(blockIdx.x, lane, S);
+        const XCfg xg = make_xcfg(g);
+        const uint32_t rb = (uint32_t)pitch * 4u, crb = (uint32_t)cpitch * 4u;
+        const uint32_t urb = (uint32_t)S * 2u;
+        const uint32_t uoff = g.off == kOob ? kOob : g.off >> 1, uoff_x = xg.foff_x == kOob ? kOob : xg.foff_x >> 1;
+
+        SRow w0, w1, w2, w3, w4;
+        zero_srow(w0); zero_srow(w1); zero_srow(w2); zero_srow(w3); zero_srow(w4);
+        bool alive[8] = {false, false, false, false, false, false, false, false};
+        const int ks = max(k0 - 1, 0);
+        CRowX ca, cm, cc;   // coarse rows km1(k), k, kp1(k)
+        load_crowx(ca, cb, (uint32_t)coarse_of_fine(2 * ks - 2, S) * crb, g, xg);
+        load_crowx(cm, cb, (uint32_t)ks * crb, g, xg);
+        // pairs k0-1 .. k1 (the first and the last only feed the 5x5 windows; outside the image they are zero rows)
+        for (int k = k0 - 1; k <= k1; k++) {
+            float be[8], bo[8], beA = 0.0f, beB = 0.0f, boA = 0.0f, boB = 0.0f;
+            const bool inside = k >= 0 && k < Sc;   // wave-uniform
+            if (inside) {
+                load_crowx(cc, cb, (uint32_t)coarse_of_fine(2 * k + 2, S) * crb, g, xg);
+                float feA, feB, foA, foB;
+                if (U16) {
+                    const float4 re = bload4(fb, uoff + (uint32_t)(2 * k) * urb), ro = bload4(fb, uoff + (uint32_t)(2 * k + 1) * urb);
+                    const uint32_t he = __float_as_uint(bload1(fb, uoff_x + (uint32_t)(2 * k) * urb));
+                    const uint32_t ho = __float_as_uint(bload1(fb, uoff_x + (uint32_t)(2 * k + 1) * urb));
+                    norm8(be, re, nk);
+                    norm8(bo, ro, nk);
+                    feA = norm_px(he & 0xFFFFu, nk); feB = norm_px(he >> 16, nk);
+                    foA = norm_px(ho & 0xFFFFu, nk); foB = norm_px(ho >> 16, nk);
+                } else {
+                    load8(be, fb, g.off + (uint32_t)(2 * k) * rb);
+                    load8(bo, fb, g.off + (uint32_t)(2 * k + 1) * rb);
+                    const float2 he = bload2(fb, xg.foff_x + (uint32_t)(2 * k) * rb), ho = bload2(fb, xg.foff_x + (uint32_t)(2 * k + 1) * rb);
+                    feA = he.x; feB = he.y; foA = ho.x; foB = ho.y;
+                }
+                float lowE[8], lowO[8], lEA, lEB, lOA, lOB;
+                lowpass_pair_x(ca, cm, cc, g, lowE, lowO, lEA, lEB, lOA, lOB);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    be[j] = be[j] - lowE[j];   // img_difference.comp:15
+                    bo[j] = bo[j] - lowO[j];
+                }
+                beA = feA - lEA; beB = feB - lEB; boA = foA - lOA; boB = foB - lOB;
+                if (k >= k0 && k < k1) {
+                    store8(bb, g.off + (uint32_t)(2 * k) * rb, be);
+                    store8(bb, g.off + (uint32_t)(2 * k + 1) * rb, bo);
+                }
+                ca = cm; cm = cc;
+            }
+            // the two band rows enter the 5-row window of squares; each completes the window of the row two above it
+#pragma unroll
+            for (int ph = 0; ph < 2; ph++) {
+                w0 = w1; w1 = w2; w2 = w3; w3 = w4;
+                if (inside) square_band_row(w4, ph ? bo : be, ph ? boA : beA, ph ? boB : beB, sg, xg.edge_ok);
+                else zero_srow(w4);
+                const int y = 2 * k + ph - 2;
+                if (y >= 2 * k0 && y < 2 * k1) sdev_row<true>(w0, w1, w2, w3, w4, sg, S, y, cov, srow0 + (size_t)y * pitch, lh, alive);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* gh = hist + (size_t)img * hist_stride;
+    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS; i += blockDim.x) {
+        const uint32_t v = lh[i];
+        if (v) atomicAdd(&gh[i], v);
+    }
+}
+
 // lowpass value at fine (x, y) for any S (generic form).
 __device__ __forceinline__ float lowpass_generic(const float* __restrict__ coarse, int cpitch, int Sc, int S, int x, int y) {
     float V[5];
@@ -890,6 +1060,20 @@ void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, fl
         hipLaunchKernelGGL((k_band_fast<2, true>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
     else
         hipLaunchKernelGGL((k_band_fast<1, true>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
+}
+
+// fine: f32 planes, or the raw uint16 pixels when u16 is set (level 0). rows_per_wave: coarse rows, a multiple of 8.
+void launch_band_sdev(hipStream_t st, const void* fine, bool u16, const float* coarse, float* band, float* sdev, const LevelDesc& lf,
+                      const LevelDesc& lc, int batch, int rows_per_wave, const uint32_t* minmax, int min_chain_exact, uint32_t* hist,
+                      size_t hist_stride, int cov) {
+    const dim3 grid = stream_grid(lf.S, lc.S, rows_per_wave, batch);
+    const float* f = reinterpret_cast<const float*>(fine);
+    if (u16)
+        hipLaunchKernelGGL((k_band_sdev_fast<true>), grid, dim3(kBlockThreads), 0, st, f, coarse, band, sdev, lf.S, lf.pitch, lf.plane, lc.S,
+                           lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact, hist, hist_stride, cov);
+    else
+        hipLaunchKernelGGL((k_band_sdev_fast<false>), grid, dim3(kBlockThreads), 0, st, f, coarse, band, sdev, lf.S, lf.pitch, lf.plane, lc.S,
+                           lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact, hist, hist_stride, cov);
 }
 
 void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc,

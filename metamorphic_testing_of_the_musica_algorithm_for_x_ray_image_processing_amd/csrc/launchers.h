@@ -54,6 +54,9 @@ void launch_reduce_u16(hipStream_t st, const uint16_t* px, const LevelDesc& li, 
                        const uint32_t* minmax, int min_chain_exact);
 void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                      int rows_per_wave, int rows_per_trip, const uint32_t* minmax, int min_chain_exact);
+void launch_band_sdev(hipStream_t st, const void* fine, bool u16, const float* coarse, float* band, float* sdev, const LevelDesc& lf,
+                      const LevelDesc& lc, int batch, int rows_per_wave, const uint32_t* minmax, int min_chain_exact, uint32_t* hist,
+                      size_t hist_stride, int cov);
 void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch);
 void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic, int rows_per_trip);
 void launch_exp_band(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch);

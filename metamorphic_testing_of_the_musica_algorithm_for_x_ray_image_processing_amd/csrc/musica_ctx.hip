@@ -93,6 +93,8 @@ struct musica_ctx {
     musica_nr_params h_nr[3];
     // rows each wavefront marches per launch, per level (heuristic, then autotuned at create)
     int rows_reduce[MUSICA_MAX_LEVELS], rows_band[MUSICA_MAX_LEVELS], rows_expand[MUSICA_MAX_LEVELS], rows_sdev[4];
+    int rows_bs[4];          // fused band + sdev kernel (coarse rows, multiples of 8)
+    bool fuse_bs;            // MUSICA_FUSE_BS=1: levels <= 3 with S >= 512, S % 8 == 0 run band and sdev as one kernel
     // tunables
     int reduce_rows, band_rows, expand_rows, sdev_rows, grad_groups, reduce_trip, band_trip, expand_trip, min_waves;
     // profiling
@@ -188,6 +190,7 @@ static void copy_rows(musica_ctx* dst, const musica_ctx* src) {
     memcpy(dst->rows_band, src->rows_band, sizeof(src->rows_band));
     memcpy(dst->rows_expand, src->rows_expand, sizeof(src->rows_expand));
     memcpy(dst->rows_sdev, src->rows_sdev, sizeof(src->rows_sdev));
+    memcpy(dst->rows_bs, src->rows_bs, sizeof(src->rows_bs));
 }
 
 // Shallow copy of the parent restricted to images [i0, i0 + nb): same buffers, pointers moved to the first image.
@@ -235,6 +238,7 @@ static musica_ctx* make_view(const musica_ctx* c, int i0, int nb) {
         v->rows_band[i] = pick_rows(c->band_rows, 1, c->lv[i].S, c->lv[i + 1].S, nb);
         v->rows_expand[i] = pick_rows(c->expand_rows, 1, c->lv[i].S, c->lv[i + 1].S, nb);
         if (i <= MUSICA_CNR_LEVEL) v->rows_sdev[i] = pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, nb);
+        if (i <= MUSICA_CNR_LEVEL) v->rows_bs[i] = pick_rows(16, 8, c->lv[i].S, c->lv[i + 1].S, nb);
     }
     return v;
 }
@@ -353,6 +357,10 @@ musica_ctx* musica_create(const musica_params* params) {
     c->use_graph = c->dag && !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", 1) != 0;
     c->graph_exec = nullptr;
     c->graph_input = nullptr;
+    // Off by default: measured at 8 x 2048^2 the fused launch takes 116 us against 46 + 65 us for band and sdev apart —
+    // both are VALU-heavy after the exact sqrt / division work, so fusing them only adds up their instruction
+    // counts (151 VGPRs, 3 waves per SIMD) while the separate launches each overlap their arithmetic with HBM.
+    c->fuse_bs = env_int("MUSICA_FUSE_BS", 0) != 0;
     c->fuse_u16 = env_int("MUSICA_U16", 1) != 0 && (N % 8) == 0 && !(params->flags & MUSICA_FLAG_GENERIC_KERNELS);
     c->norm_valid = false;
     ok = ok && dalloc(c, &c->d_input, B * N * N);
@@ -396,6 +404,7 @@ musica_ctx* musica_create(const musica_params* params) {
         c->rows_band[i] = pick_rows(c->band_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
         c->rows_expand[i] = pick_rows(c->expand_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
         if (i <= MUSICA_CNR_LEVEL) c->rows_sdev[i] = pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, c->B);
+        if (i <= MUSICA_CNR_LEVEL) c->rows_bs[i] = pick_rows(16, 8, c->lv[i].S, c->lv[i + 1].S, c->B);
     }
     const bool tune = !(params->flags & MUSICA_FLAG_NO_AUTOTUNE) && env_int("MUSICA_AUTOTUNE", 1) && !c->generic;
     const int groups = pick_groups(c);
@@ -499,6 +508,16 @@ static void run_band_level(musica_ctx* c, int i, int rows) {
         return;
     }
     launch_band(c->cur, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, rows, c->generic, c->band_trip);
+}
+static bool bs_fused_level(const musica_ctx* c, int i) {
+    return c->fuse_bs && !c->generic && i <= MUSICA_CNR_LEVEL && c->lv[i].S >= 512 && (c->lv[i].S % 8) == 0;
+}
+// band + sdev + noise histogram of level i in one launch
+static void run_band_sdev_level(musica_ctx* c, int i, int rows) {
+    const bool u16 = i == 0 && c->fuse_u16;
+    launch_band_sdev(c->cur, u16 ? (const void*)c->cur_input : (const void*)level_input(c, i), u16, c->d_down[i], c->d_band[i], c->d_sdev[i],
+                     c->lv[i], c->lv[i + 1], c->B, rows, c->d_minmax, c->min_chain_exact, c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS,
+                     (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov);
 }
 static void run_sdev_level(musica_ctx* c, int i, int rows) {
     launch_sdev_hist(c->cur, c->d_band[i], c->d_sdev[i], c->lv[i], c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS,
@@ -614,6 +633,7 @@ static void enqueue_dag(musica_ctx* c) {
     c->cur = c->side;
     for (int i = 2; i < L; i++) {
         { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
+        if (bs_fused_level(c, i)) { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_band_sdev_level(c, i, c->rows_bs[i]); continue; }
         { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
         if (i <= MUSICA_CNR_LEVEL) { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
     }
@@ -624,10 +644,11 @@ static void enqueue_dag(musica_ctx* c) {
     hipEventRecord(c->ev_join, c->side);
     // main stream: the bandwidth-bound kernels of levels 0 and 1
     c->cur = c->stream;
-    { Span sp(c, MUSICA_KERNEL_BAND_L0); run_band_level(c, 0, c->rows_band[0]); }
-    { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, 0, c->rows_sdev[0]); }
-    { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, 1, c->rows_band[1]); }
-    { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, 1, c->rows_sdev[1]); }
+    for (int i = 0; i < 2; i++) {
+        if (bs_fused_level(c, i)) { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_sdev_level(c, i, c->rows_bs[i]); continue; }
+        { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
+        { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
+    }
     hipStreamWaitEvent(c->stream, c->ev_join, 0);
     {
         Span sp(c, MUSICA_KERNEL_CURVES);
@@ -762,11 +783,13 @@ static void autotune(musica_ctx* c) {
     static const int cand_sdev[] = {16, 32, 64};
     for (int i = 0; i < c->L; i++) {
         if (c->lv[i].S < 512 || (c->lv[i].S % 8) != 0) continue;   // small levels are launch-bound: keep the heuristic
-        struct { int* slot; const int* cand; int ncand; void (*fn)(musica_ctx*, int, int); bool use; } jobs[4] = {
+        static const int cand_bs[] = {8, 16, 32};
+        struct { int* slot; const int* cand; int ncand; void (*fn)(musica_ctx*, int, int); bool use; } jobs[5] = {
+            {i <= MUSICA_CNR_LEVEL ? &c->rows_bs[i] : nullptr, cand_bs, 3, run_band_sdev_level, bs_fused_level(c, i)},
             {&c->rows_reduce[i], cand_reduce, 5, run_reduce_level, true},
-            {&c->rows_band[i], cand_pair, 4, run_band_level, true},
+            {&c->rows_band[i], cand_pair, 4, run_band_level, !bs_fused_level(c, i)},
             {&c->rows_expand[i], cand_pair, 4, run_expand_level, true},
-            {i <= MUSICA_CNR_LEVEL ? &c->rows_sdev[i] : nullptr, cand_sdev, 3, run_sdev_level, i <= MUSICA_CNR_LEVEL},
+            {i <= MUSICA_CNR_LEVEL ? &c->rows_sdev[i] : nullptr, cand_sdev, 3, run_sdev_level, i <= MUSICA_CNR_LEVEL && !bs_fused_level(c, i)},
         };
         for (auto& j : jobs) {
             if (!j.use) continue;

@@ -167,6 +167,20 @@ def test_image_groups_give_the_same_bits(ob, flags, monkeypatch):
     grp.cleanup()
 
 
+@pytest.mark.parametrize("n,levels,batch", [(1024, 6, 1), (2048, 6, 2), (1544, 0, 1)])
+def test_fused_band_sdev_kernel_gives_the_same_bits(ob, n, levels, batch, monkeypatch):
+    """MUSICA_FUSE_BS=1: band, 5x5 RMS and noise histogram of the large levels in one launch (k_band_sdev_fast,
+    raw uint16 input at level 0) against the oracle; several strips, partial last strip (1544 = 3 x 512 + 8)."""
+    monkeypatch.setenv("MUSICA_FUSE_BS", "1")
+    px = np.stack([phantom(n, 700 + k) for k in range(batch)])
+    p = _proc(n, levels, batch=batch)
+    assert p.execute(px)
+    for k in range(batch):
+        o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[k])
+        _compare_all(p, o, ob, idx=k, tag="fused image %d: " % k)
+    p.cleanup()
+
+
 def test_exact_math_shortcuts_on_the_device():
     """csrc/exact_math.h: the rsq-based sqrt (single and 8-wide grouped, +0 mixed in) against sqrtf over all
     2^32 float patterns, and the shortcut normalisation against the literal one over every (pixel, min, max)."""
