@@ -231,6 +231,24 @@ def main():
             if not proc.execute(px):
                 raise SystemExit("musica_execute failed: " + mp.last_error())
         e2e = 3 * batch * n * n / 1e6 / (time.perf_counter() - te0)
+        # BASELINE configs[1] beside the batched workload: ONE image of the same size per execute, as the reference's
+        # VulkanProcessing::execute is called (a latency-bound chain of ~33 dependent kernels; reported, never `value`)
+        single = None
+        if batch > 1 and world == 1:
+            p1 = mp.MusicaProcessing(device=local_rank)
+            if p1.init(n, levels=levels, batch=1, flags=flags):
+                p1.upload(px[:1])
+                for _ in range(max(args.warmup, 3)):
+                    p1.execute_device()
+                p1.sync()
+                ts0 = time.perf_counter()
+                for _ in range(args.steps):
+                    p1.execute_device()
+                p1.sync()
+                ts = (time.perf_counter() - ts0) / args.steps
+                single = {"workload": "1 x %dx%d per execute, %d-level pyramid (BASELINE configs[1] shape)" % (n, n, levels),
+                          "value": round(n * n / 1e6 / ts, 1), "unit": "MP/s", "ms_per_image": round(ts * 1e3, 4)}
+                p1.cleanup()
         # CPU baseline: the oracle (a port — the reference has no CPU path), all host cores, bounded sample
         cpu = None
         if args.cpu_seconds > 0 and world == 1:
@@ -263,10 +281,11 @@ def main():
                        "kernel_events_in_timed_region": kernel_events,
                        "stats_gathered": int(st.shape[0])},
             "roofline": roofline, "roofline_4096": roofline_4096, "cpu_baseline": cpu, "kernels": kernels,
-            "e2e_host_MPps": round(e2e, 1),
+            "e2e_host_MPps": round(e2e, 1), "single_image": single,
         }
     proc.cleanup()
     if distributed:
+        dist.barrier()          # rank 0 measured the stand-alone kernel after the timed region: leave together
         dist.destroy_process_group()
     if result is not None:
         print(json.dumps(result))
