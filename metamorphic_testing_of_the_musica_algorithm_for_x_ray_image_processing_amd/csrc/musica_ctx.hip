@@ -627,6 +627,17 @@ static void enqueue_dag(musica_ctx* c) {
     { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, 1, c->rows_reduce[1]); }
     hipEventRecord(c->ev_fork, c->stream);
     hipStreamWaitEvent(c->side, c->ev_fork, 0);
+    // main stream first: the bandwidth-bound kernels of levels 0 and 1. Issue order matters — a graph replay enqueues
+    // its nodes in capture order at ~3.5 us each, so whatever is issued last starts tens of microseconds late
+    // (rocprofv3 timeline: with the side chain first, level-0 band started 45 us after its input was ready).
+    // Measured and not kept: a high-priority side stream (no effect: the long-lived wavefronts of the streaming
+    // kernels hold the wave slots either way) and CU-masked streams (32 / 224 CU split: 5 % slower).
+    c->cur = c->stream;
+    for (int i = 0; i < 2; i++) {
+        if (bs_fused_level(c, i)) { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_sdev_level(c, i, c->rows_bs[i]); continue; }
+        { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
+        { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
+    }
     // side stream: everything of levels >= 2 that does not need a histogram-derived curve —
     // reduce / band / sdev of levels 2.., then the expand slots of levels L-1 .. 3 (constant gain above
     // level 3, range gain at level 3: neither reads a curve, src/vk_processing.cpp:259-293)
@@ -642,13 +653,7 @@ static void enqueue_dag(musica_ctx* c) {
         run_expand_level(c, lvl, c->rows_expand[lvl]);
     }
     hipEventRecord(c->ev_join, c->side);
-    // main stream: the bandwidth-bound kernels of levels 0 and 1
     c->cur = c->stream;
-    for (int i = 0; i < 2; i++) {
-        if (bs_fused_level(c, i)) { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_sdev_level(c, i, c->rows_bs[i]); continue; }
-        { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
-        { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
-    }
     hipStreamWaitEvent(c->stream, c->ev_join, 0);
     {
         Span sp(c, MUSICA_KERNEL_CURVES);
