@@ -181,6 +181,24 @@ def test_fused_band_sdev_kernel_gives_the_same_bits(ob, n, levels, batch, monkey
     p.cleanup()
 
 
+@pytest.mark.parametrize("batch", [1, 3])
+def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
+    """MUSICA_DAG = 0 (one in-order stream, the reference's order), 1 (two streams), 2 (one stream per level),
+    graph replay and eager: every form against the oracle, twice in a row (histograms re-cleared, events re-armed)."""
+    n, levels = 1032, 6
+    px = np.stack([phantom(n, 800 + k) for k in range(batch)])
+    want = [ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[k]) for k in range(batch)]
+    for dag in ("0", "1", "2"):
+        for flags in (0, mp.FLAG_NO_GRAPH):
+            monkeypatch.setenv("MUSICA_DAG", dag)
+            p = _proc(n, levels, batch=batch, flags=flags)
+            for rep in range(2):
+                assert p.execute(px)
+            for k in range(batch):
+                _compare_all(p, want[k], ob, idx=k, tag="dag %s flags %d image %d: " % (dag, flags, k))
+            p.cleanup()
+
+
 def test_exact_math_shortcuts_on_the_device():
     """csrc/exact_math.h: the rsq-based sqrt (single and 8-wide grouped, +0 mixed in) against sqrtf over all
     2^32 float patterns, and the shortcut normalisation against the literal one over every (pixel, min, max)."""
