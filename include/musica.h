@@ -105,7 +105,7 @@ typedef struct musica_stats {
  * (imageSize = 3072 in test/standalone/main.cpp:31; L = ceil(log2 N) in
  * src/vk_processing.cpp:1989). */
 typedef struct musica_params {
-    uint32_t image_size; /* N; N >= 16 */
+    uint32_t image_size; /* N; 16 <= N <= 16384 (a level-0 f32 plane must stay below 2 GiB: 32-bit buffer offsets) */
     uint32_t levels;     /* L; 0 => ceil(log2 N) (reference rule); else 4 <= L <= ceil(log2 N) */
     uint32_t batch;      /* images per execute call, 0 => 1 (reference: 1) */
     int32_t device;      /* HIP device ordinal */

@@ -324,7 +324,9 @@ void musica_destroy(musica_ctx* c) {
 musica_ctx* musica_create(const musica_params* params) {
     if (!params) { fail("musica_create: params is NULL"); return nullptr; }
     const uint32_t N = params->image_size;
-    if (N < 16 || N > 32768) { fail("musica_create: image_size %u out of range [16, 32768]", N); return nullptr; }
+    // 16384: a level-0 f32 plane is then 1 GiB — the kernels address planes through buffer descriptors with 32-bit
+    // byte offsets and use bit 31 as the "nothing to load" marker, so a plane must stay below 2 GiB
+    if (N < 16 || N > 16384) { fail("musica_create: image_size %u out of range [16, 16384]", N); return nullptr; }
     uint32_t Lref = 0;
     while ((1u << Lref) < N) Lref++;  // pyramidLevels = ceil(log2(imageSize)), src/vk_processing.cpp:1989
     const uint32_t L = params->levels ? params->levels : Lref;

@@ -199,6 +199,51 @@ def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
             p.cleanup()
 
 
+def test_largest_baseline_size_matches_the_oracle(ob):
+    """BASELINE configs[4]: 8192 x 8192, 12-bit, 10-level pyramid — final pixels, histograms, curves and the level-0
+    images against the oracle (which needs a few seconds and ~4 GB for it)."""
+    n, levels = 8192, 10
+    px = phantom(n, 5, bits=12)
+    o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px)
+    p = _proc(n, levels)
+    assert p.execute(px)
+    assert np.array_equal(p.out_pixels(0), o.out_pixels())
+    _same(p.image(mp.IMG_GRADED, 0, 0), o.image(ob.IMG_GRADED), "graded 8192")
+    _same(p.image(mp.IMG_BANDPASS, 0, 0), o.image(ob.IMG_BANDPASS, 0), "bandpass[0] 8192")
+    _same(p.image(mp.IMG_EXPAND, 0, 0), o.image(ob.IMG_EXPAND, 0), "expand[0] 8192")
+    for i in range(4):
+        assert np.array_equal(p.noise_hist(i, 0), o.noise_hist(i))
+    assert np.array_equal(p.grad_hist(0), o.grad_hist())
+    gc, gw = p.grad_curve(0)
+    oc, ow = o.grad_curve()
+    assert np.array_equal(gc, oc) and gw == ow
+    p.cleanup()
+
+
+def test_maximum_size_runs_and_is_deterministic():
+    """The largest accepted side (16384: a 1 GiB level-0 plane, 32-bit buffer offsets up to 2^30) — no oracle at this
+    size in the test budget; properties instead: two executes give identical bits, the output is finite and spans
+    the 8-bit range, the min / max scalars are those of the input; one more pixel of side is refused."""
+    n = 16384
+    rng = np.random.default_rng(3)
+    base = phantom(2048, 9)
+    px = np.tile(base, (8, 8))
+    px = (px.astype(np.int64) + rng.integers(0, 8, size=(n, 1))).clip(1, 65535).astype(np.uint16)   # rows differ: no exact tiling
+    p = _proc(n, 6)
+    assert p.execute(px)
+    a = p.out_pixels(0).copy()
+    mn, mx = p.minmax(0)
+    assert mx == np.floor(np.sqrt(float(px.max()))) and mn == 0.0          # 16384 is not a power of 8: min chain -> 0
+    assert p.execute(px)
+    assert np.array_equal(a, p.out_pixels(0))
+    g = p.image(mp.IMG_GRADED, 0, 0)
+    assert np.isfinite(g).all() and a.min() < 32 and a.max() > 200
+    p.cleanup()
+    q = mp.MusicaProcessing()
+    assert not q.init(n + 8, levels=6)
+    assert "out of range" in mp.last_error()
+
+
 def test_exact_math_shortcuts_on_the_device():
     """csrc/exact_math.h: the rsq-based sqrt (single and 8-wide grouped, +0 mixed in) against sqrtf over all
     2^32 float patterns, and the shortcut normalisation against the literal one over every (pixel, min, max)."""
