@@ -199,6 +199,31 @@ def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
             p.cleanup()
 
 
+def _random_cases(count, seed):
+    """(N, levels, phantom seed, bits, noise) drawn once from a fixed generator: odd sizes, sizes around the strip
+    (512) and vector (8) boundaries, the smallest accepted sides, reference-rule and explicit level counts."""
+    rng = np.random.default_rng(seed)
+    pool = [16, 17, 23, 24, 31, 32, 40, 63, 64, 65, 72, 100, 127, 128, 136, 255, 256, 264, 504, 511, 512, 513, 520,
+            528, 600, 776, 1000, 1016, 1024, 1032, 1096, 1536, 1544]
+    cases = []
+    for _ in range(count):
+        n = int(rng.choice(pool))
+        lref = int(np.ceil(np.log2(n)))
+        levels = int(rng.choice([0, 4, min(5, lref), min(6, lref)]))
+        cases.append((n, levels, int(rng.integers(1, 10_000)), int(rng.choice([12, 16])), float(rng.choice([0.0, 1.0, 4.0]))))
+    return cases
+
+
+@pytest.mark.parametrize("n,levels,seed,bits,noise", _random_cases(40, 2024))
+def test_random_configurations_match_the_oracle(ob, n, levels, seed, bits, noise):
+    px = phantom(n, seed, bits=bits, noise=noise)
+    o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px)
+    p = _proc(n, levels)
+    assert p.execute(px), mp.last_error()
+    _compare_all(p, o, ob, tag="N=%d L=%d seed=%d: " % (n, levels, seed))
+    p.cleanup()
+
+
 def test_largest_baseline_size_matches_the_oracle(ob):
     """BASELINE configs[4]: 8192 x 8192, 12-bit, 10-level pyramid — final pixels, histograms, curves and the level-0
     images against the oracle (which needs a few seconds and ~4 GB for it)."""
