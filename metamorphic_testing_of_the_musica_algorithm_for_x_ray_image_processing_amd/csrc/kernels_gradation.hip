@@ -75,7 +75,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
     const Buf cb = make_buf(a.cnr + (size_t)img * a.cnrPlane, a.cnrPlane * 4);
     const int lane = threadIdx.x & 63;
     const int N = a.N;
-    const int c = blockIdx.x * 256 + lane * 4;
+    // the four wavefronts of a workgroup sit side by side (1024 columns x 16 rows per group): a workgroup reads 4 KiB
+    // of every row it touches instead of four separate 1 KiB pieces
+    const int c = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 256 + lane * 4;
     const int valid = min(max(N - c, 0), 4);                  // in-image columns among the lane's 4
     const uint32_t coff = c < N ? (uint32_t)c * 4u : kOob;
     const uint32_t rb = (uint32_t)a.pitch * 4u, crb = (uint32_t)a.cnrPitch * 4u;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
     // byte offset of the lane's cnr column (out of the cnr image reads 0, Q1)
     const int cx0 = c / a.cnrScale;
     const uint32_t cxoff = (c < N && cx0 < a.cnrS) ? (uint32_t)cx0 * 4u : kOob;
-    const int g0 = (blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)) * a.groups_per_wave;
+    const int g0 = blockIdx.y * a.groups_per_wave;
     for (int gi = 0; gi < a.groups_per_wave; gi++) {
         const int yb = (g0 + gi) * kHistArea;
         if (yb >= N) break;  // wave-uniform
@@ -335,10 +337,10 @@ __global__ __launch_bounds__(256) void k_grad_apply(const float* __restrict__ in
 // ======================================================================================
 
 void launch_grad_hist(hipStream_t st, const GradArgs& a, int batch) {
-    const int col_blocks = (a.N + 255) / 256;
+    const int col_blocks = (a.N + 256 * kWavesPerBlock - 1) / (256 * kWavesPerBlock);
     const int groups = (a.N + kHistArea - 1) / kHistArea;
     const int wave_rows = (groups + a.groups_per_wave - 1) / a.groups_per_wave;
-    const dim3 grid(col_blocks, (wave_rows + kWavesPerBlock - 1) / kWavesPerBlock, batch);
+    const dim3 grid(col_blocks, wave_rows, batch);
     const bool raw = a.raw != nullptr && (a.N & 3) == 0;
     if ((a.cnrScale & 7) == 0) {
         if (raw) hipLaunchKernelGGL((k_grad_hist<true, true>), grid, dim3(kBlockThreads), 0, st, a);
