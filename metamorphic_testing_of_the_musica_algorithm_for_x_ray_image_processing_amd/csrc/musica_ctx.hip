@@ -381,10 +381,10 @@ musica_ctx* musica_create(const musica_params* params) {
     ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
-    // one image: the per-level form wins (0.225 vs 0.237 ms at 2048^2: shorter dependent chain); a batch: the two-stream
-    // form (0.564 vs 0.571 ms at 8 x 2048^2: the reduce chain of the per-level form crawls among the big kernels, and
-    // running the whole reduce chain first to avoid that costs 0.69 ms)
-    c->dag = env_int("MUSICA_DAG", c->B == 1 ? 2 : 1);
+    // little work per step (<= 8 Mpixel): the per-level form wins (one 2048^2 image: 0.229 vs 0.241 ms, shorter dependent
+    // chain); more: the two-stream form (8 x 2048^2: 0.564 vs 0.571 ms; one 8192^2: 1.05 vs 1.11 ms — the reduce chain
+    // of the per-level form crawls among the big kernels, and running the whole reduce chain first costs 0.69 ms)
+    c->dag = env_int("MUSICA_DAG", (size_t)c->B * N * N <= ((size_t)8 << 20) ? 2 : 1);
     if (c->dag < 0 || c->dag > 2) c->dag = 1;
     for (int i = 0; i < MUSICA_MAX_LEVELS; i++) { c->lvs[i] = nullptr; c->ev_r[i] = nullptr; c->ev_l[i] = nullptr; }
     ok = ok && create_level_streams(c);
