@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--kernel-events", action="store_true",
                     help="bracket the metric kernel with HIP events inside the timed steps (forces eager launches: stream "
                          "capture drops event records, so the default timed region replays the hipGraph without events)")
+    ap.add_argument("--no-single-image", action="store_true", help="skip the one-image-per-execute measurement (keeps a kernel trace of the run pure)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel event passes after the timed region")
     args = ap.parse_args()
 
@@ -234,7 +235,7 @@ def main():
         # BASELINE configs[1] beside the batched workload: ONE image of the same size per execute, as the reference's
         # VulkanProcessing::execute is called (a latency-bound chain of ~33 dependent kernels; reported, never `value`)
         single = None
-        if batch > 1 and world == 1:
+        if batch > 1 and world == 1 and not args.no_single_image:
             p1 = mp.MusicaProcessing(device=local_rank)
             if p1.init(n, levels=levels, batch=1, flags=flags):
                 p1.upload(px[:1])
