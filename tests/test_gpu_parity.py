@@ -199,6 +199,26 @@ def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
             p.cleanup()
 
 
+@pytest.mark.parametrize("env", [{"MUSICA_REDUCE_TRIP": "0"}, {"MUSICA_REDUCE_TRIP": "1"}, {"MUSICA_REDUCE_TRIP": "2"},
+                                 {"MUSICA_REDUCE_TRIP": "4"}, {"MUSICA_REDUCE_TRIP": "-2"}, {"MUSICA_REDUCE_TRIP": "-3"},
+                                 {"MUSICA_BAND_TRIP": "1"}, {"MUSICA_EXPAND_TRIP": "2"}, {"MUSICA_U16": "0"},
+                                 {"MUSICA_AUTOTUNE": "0", "MUSICA_REDUCE_ROWS": "4", "MUSICA_BAND_ROWS": "2", "MUSICA_EXPAND_ROWS": "2", "MUSICA_SDEV_ROWS": "16"},
+                                 {"MUSICA_AUTOTUNE": "0", "MUSICA_REDUCE_ROWS": "32", "MUSICA_BAND_ROWS": "16", "MUSICA_EXPAND_ROWS": "16", "MUSICA_SDEV_ROWS": "64", "MUSICA_MIN_WAVES": "1"}],
+                         ids=lambda e: ",".join("%s=%s" % (k[7:], v) for k, v in e.items()))
+def test_kernel_variants_and_launch_geometries_give_the_same_bits(ob, env, monkeypatch):
+    """The alternative forms of the streaming kernels kept in the library (LDS-tiled, rows-per-trip, rotating
+    registers, stored normalized image) and extreme rows-per-wavefront choices: all bit-identical to the oracle."""
+    n, levels = 1024, 6
+    px = phantom(n, 900)
+    o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    p = _proc(n, levels)
+    assert p.execute(px)
+    _compare_all(p, o, ob, tag=str(env) + ": ")
+    p.cleanup()
+
+
 def _random_cases(count, seed):
     """(N, levels, phantom seed, bits, noise) drawn once from a fixed generator: odd sizes, sizes around the strip
     (512) and vector (8) boundaries, the smallest accepted sides, reference-rule and explicit level counts."""
