@@ -11,6 +11,7 @@ parameter grids and the metric definitions, can drive the library in-process or 
 exactly like `run_process` (:200-214), and exposes the relations as data so tests can assert them on
 phantoms (the reference's raw_images/ are missing blobs).
 """
+import csv
 import math
 import os
 import subprocess
@@ -253,3 +254,66 @@ def run_study(raw, runner, rng=None, shutters=None, translations=None, rotations
     for f in factors:
         add("pn_%s" % f, apply_quantum_noise(raw, f, rng))
     return rows
+
+
+# ---- command line: the reference's three CSV files (script.py:223-330) -------------------------
+CSV_HEADER = ['raw file', 'alteration', 'altered vs unaltered mse', 'altered vs unaltered ssim', 'altered vs unaltered histogram distance',
+              'altered vs reference mse', 'altered vs reference ssim', 'altered vs reference histogram distance',
+              'normalized altered vs reference mse', 'normalized altered vs reference ssim',
+              'normalized altered vs reference histogram distance']
+
+
+def write_study_csvs(rows, out_dir, raw_name, mean_cnr=True):
+    """direct_robustness.csv / reg_based_robustness.csv with the reference's column layout. The six "vs reference"
+    columns compare with the vendor-processed image, which the reference tree does not ship (missing blobs): they
+    stay empty. mean_cnr.csv adds what test/mean_cnr/script.py reports per alteration."""
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "direct_robustness.csv"), "w", newline="") as fd, \
+            open(os.path.join(out_dir, "reg_based_robustness.csv"), "w", newline="") as fr:
+        wd, wr = csv.writer(fd), csv.writer(fr)
+        wd.writerow(CSV_HEADER)
+        wr.writerow(CSV_HEADER)
+        for r in rows:
+            if r["alteration"] == "unaltered":
+                continue
+            d = r["direct"]
+            wd.writerow([raw_name, r["alteration"], d["mse"], d["ssim"], d["hist_distance"]] + [""] * 6)
+            if r["registered"] is not None:
+                g = r["registered"]
+                wr.writerow([raw_name, r["alteration"], g["mse"], g["ssim"], g["hist_distance"]] + [""] * 6)
+    if mean_cnr:
+        with open(os.path.join(out_dir, "mean_cnr.csv"), "w", newline="") as fc:
+            wc = csv.writer(fc)
+            wc.writerow(["raw file", "alteration", "mean cnr"])
+            for r in rows:
+                wc.writerow([raw_name, r["alteration"], r["mean_cnr"]])
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="Metamorphic study of one raw image (or a seeded phantom) on the HIP MUSICA path")
+    ap.add_argument("--raw", help="raw file: 256-byte header + N*N little-endian uint16 (test/standalone/main.cpp:54-75)")
+    ap.add_argument("--phantom-seed", type=int, default=1, help="seed of the synthetic phantom used when --raw is absent")
+    ap.add_argument("--size", type=int, default=3072, help="image side N (the reference's CLI fixes 3072)")
+    ap.add_argument("--levels", type=int, default=0)
+    ap.add_argument("--out", default="out", help="directory of the CSV files")
+    ap.add_argument("--cli", action="store_true", help="run every image through the musica-standalone process (run_process, script.py:200-214)")
+    args = ap.parse_args(argv)
+    if args.raw:
+        from .processing import read_raw
+        raw = read_raw(args.raw, args.size)
+        name = os.path.basename(args.raw)
+    else:
+        from .phantom import phantom
+        raw = phantom(args.size, args.phantom_seed, noise=4.0)
+        name = "phantom_%d_seed%d" % (args.size, args.phantom_seed)
+    runner = Runner(args.size, args.levels, use_cli=args.cli)
+    rows = run_study(raw, runner, rng=np.random.default_rng(0))
+    runner.close()
+    write_study_csvs(rows, args.out, name, mean_cnr=not args.cli)
+    print("wrote %d alterations to %s" % (len(rows) - 1, args.out))
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -156,3 +156,21 @@ def test_study_relations_on_gpu_and_cli_equals_inprocess(tmp_path):
     b = cli.run(raw, str(tmp_path))
     assert np.array_equal(a, b)
     runner.close()
+
+
+def test_study_csv_files_have_the_reference_layout(ob, tmp_path):
+    """direct_robustness.csv / reg_based_robustness.csv as test/metamorphic_test/script.py:223-330 lays them out (the
+    vendor-reference columns stay empty: those images are missing blobs of the reference tree)."""
+    import csv
+    n, levels = 256, 5
+    rows = H.run_study(phantom(n, 12, noise=4.0), OracleRunner(ob, n, levels), rng=np.random.default_rng(1),
+                       shutters=[30], translations=[40], rotations=[9], sigmas=[16.0], factors=[0.05])
+    H.write_study_csvs(rows, str(tmp_path), "phantom.raw")
+    direct = list(csv.reader(open(tmp_path / "direct_robustness.csv")))
+    reg = list(csv.reader(open(tmp_path / "reg_based_robustness.csv")))
+    cnr = list(csv.reader(open(tmp_path / "mean_cnr.csv")))
+    assert direct[0] == H.CSV_HEADER and reg[0] == H.CSV_HEADER and len(direct[0]) == 11
+    assert [r[1] for r in direct[1:]] == ["c_sh_30", "t_x_40", "t_y_40", "r_9", "gn_16.0", "pn_0.05"]
+    assert [r[1] for r in reg[1:]] == ["c_sh_30", "t_x_40", "t_y_40", "r_9"]          # noise has no registration
+    assert all(r[0] == "phantom.raw" and 0.0 <= float(r[2]) <= 1.0 and r[5:] == [""] * 6 for r in direct[1:])
+    assert cnr[1][1] == "unaltered" and float(cnr[1][2]) > 0
