@@ -441,8 +441,18 @@ __global__ __launch_bounds__(256) void k_stats(const float* __restrict__ cnr, in
     const int img = blockIdx.x;
     const float* p = cnr + (size_t)img * plane;
     double acc = 0.0;
-    for (int y = 0; y < S; y++)
-        for (int x = threadIdx.x; x < S; x += blockDim.x) acc += (double)p[(size_t)y * pitch + x];
+    for (int x = threadIdx.x; x < S; x += blockDim.x) {
+        const float* col = p + x;
+        int y = 0;
+        for (; y + 8 <= S; y += 8) {   // eight independent loads in flight per thread (one per trip cost 115 us at S = 256)
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = col[(size_t)(y + k) * pitch];
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc += (double)v[k];
+        }
+        for (; y < S; y++) acc += (double)col[(size_t)y * pitch];
+    }
     part[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o >= 1; o >>= 1) {
