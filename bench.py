@@ -269,7 +269,20 @@ def main():
                 if time.perf_counter() - tc0 >= args.cpu_seconds or done >= 4096:
                     break
             tc = time.perf_counter() - tc0
-            cpu = {"value": round(done * n * n / 1e6 / tc, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+            # BASELINE configs[0] as well: one 512 x 512 image, 4 levels, literal 25-tap order, one thread (the semantic baseline)
+            ob.set_threads(1)
+            p0 = phantom(512, 1)
+            o0 = ob.Oracle(512, 4, ob.ORDER_REFERENCE, 0)
+            o0.execute(p0)
+            n0, t00 = 0, time.perf_counter()
+            while n0 < 64 and (n0 == 0 or time.perf_counter() - t00 < 2.0):
+                o0.execute(p0)
+                n0 += 1
+            t0c = time.perf_counter() - t00
+            ob.set_threads(cores)
+            configs0 = {"value": round(n0 * 512 * 512 / 1e6 / t0c, 2), "unit": "MP/s", "cores": 1,
+                        "sample": "%d x 512x512 images, 4-level pyramid, oracle MUSICA_ORDER_REFERENCE (literal 25-tap stencils), 1 thread, %.1f s" % (n0, t0c)}
+            cpu = {"value": round(done * n * n / 1e6 / tc, 2), "unit": "MP/s", "cores": cores, "kind": "port", "configs0_single_thread": configs0,
                    "sample": "%d x %dx%d images, %d-level pyramid, oracle MUSICA_ORDER_FAST with OpenMP on %d threads, %.1f s"
                              % (done, n, n, levels, cores, tc)}
         st = gathered.cpu().numpy()
