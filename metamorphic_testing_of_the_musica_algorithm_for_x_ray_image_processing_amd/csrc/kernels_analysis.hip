@@ -323,15 +323,14 @@ __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long k
 
 // grid (levels, batch), 256 threads. Levels 0..3 take the argmax of their noise histogram; every
 // level then builds its contrast curve (src/vk_processing.cpp:2284-2320).
-__global__ __launch_bounds__(256) void k_noise_curves(const uint32_t* __restrict__ hist, size_t hist_stride,
-                                                      musica_hist_max_point* __restrict__ maxpts, DevCurve* __restrict__ curves,
-                                                      const musica_contrast_params* __restrict__ cparams, int levels,
-                                                      DevCurveLut* __restrict__ luts) {
+__device__ __forceinline__ void noise_curves_block(int level, int img, const uint32_t* __restrict__ hist, size_t hist_stride,
+                                                   musica_hist_max_point* __restrict__ maxpts, DevCurve* __restrict__ curves,
+                                                   const musica_contrast_params* __restrict__ cparams, int levels,
+                                                   DevCurveLut* __restrict__ luts) {
     __shared__ unsigned long long scratch[16];
     __shared__ float sx[kCurveCap];
     __shared__ int sbucket[kCurveCap];
     __shared__ int sok;
-    const int level = blockIdx.x, img = blockIdx.y;
     musica_hist_max_point mp;
     mp.maxValue = 0; mp.maxBin = 0;
     if (level <= MUSICA_CNR_LEVEL) {
@@ -412,6 +411,46 @@ __global__ __launch_bounds__(256) void k_noise_curves(const uint32_t* __restrict
         lut->ok = (uint32_t)sok;
         lut->pad0 = lut->pad1 = 0;
     }
+}
+
+__global__ __launch_bounds__(256) void k_noise_curves(const uint32_t* __restrict__ hist, size_t hist_stride,
+                                                      musica_hist_max_point* __restrict__ maxpts, DevCurve* __restrict__ curves,
+                                                      const musica_contrast_params* __restrict__ cparams, int levels,
+                                                      DevCurveLut* __restrict__ luts) {
+    noise_curves_block(blockIdx.x, blockIdx.y, hist, hist_stride, maxpts, curves, cparams, levels, luts);
+}
+
+// K12 + K13 and K15 in one launch: workgroups 0 .. levels-1 of an image build that level's curve, the others each
+// normalise one 32 x 8 tile of the level-3 sdev image. img_cnr.comp only needs the level-3 noise mode, so a tile
+// workgroup takes the argmax of that histogram itself (2048 bins, the same first-maximum key as K12) instead of
+// waiting for another workgroup: one launch and one dependency less on the step's critical path.
+__global__ __launch_bounds__(256) void k_curves_cnr(const uint32_t* __restrict__ hist, size_t hist_stride,
+                                                    musica_hist_max_point* __restrict__ maxpts, DevCurve* __restrict__ curves,
+                                                    const musica_contrast_params* __restrict__ cparams, int levels,
+                                                    DevCurveLut* __restrict__ luts, const float* __restrict__ sdev, float* __restrict__ cnr,
+                                                    int S, int pitch, size_t plane, int tiles_x) {
+    const int img = blockIdx.y;
+    if ((int)blockIdx.x < levels) {   // block-uniform
+        noise_curves_block(blockIdx.x, img, hist, hist_stride, maxpts, curves, cparams, levels, luts);
+        return;
+    }
+    __shared__ unsigned long long scratch2[16];
+    const uint32_t* h = hist + (size_t)img * hist_stride + (size_t)MUSICA_CNR_LEVEL * MUSICA_NOISE_BINS;
+    unsigned long long k = 0ull;
+    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS; i += blockDim.x) {
+        const unsigned long long ki = argmax_key(h[i], (uint32_t)i);
+        k = ki > k ? ki : k;
+    }
+    k = block_max_u64(k, scratch2);
+    const uint32_t maxBin = k ? 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull) : 0u;
+    float ref = (float)maxBin * (1.0f / (float)MUSICA_NOISE_BINS) * kMaxNoiseValue;            // img_cnr.comp:22
+    if (ref == 0.0f) ref = (1.0f / (float)MUSICA_NOISE_BINS) * kMaxNoiseValue;                  // :25
+    const int t = (int)blockIdx.x - levels;
+    const int x = (t % tiles_x) * 32 + (int)(threadIdx.x & 31), y = (t / tiles_x) * 8 + (int)(threadIdx.x >> 5);
+    if (x >= S || y >= S) return;
+    const size_t o = (size_t)img * plane + (size_t)y * pitch + x;
+    const float v = sdev[o] / ref;                                                              // :31
+    cnr[o] = v / kMaxCnrValue;                                                                  // :43
 }
 
 // ---- K15 ------------------------------------------------------------------------------
@@ -532,6 +571,14 @@ void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& 
 void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves,
                          const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts) {
     hipLaunchKernelGGL(k_noise_curves, dim3(levels, batch), dim3(256), 0, st, hist, hist_stride, maxpts, curves, cparams, levels, luts);
+}
+
+void launch_curves_cnr(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves,
+                       const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const float* sdev, float* cnr,
+                       const LevelDesc& l3) {
+    const int tiles_x = (l3.S + 31) / 32, tiles_y = (l3.S + 7) / 8;
+    hipLaunchKernelGGL(k_curves_cnr, dim3(levels + tiles_x * tiles_y, batch), dim3(256), 0, st, hist, hist_stride, maxpts, curves, cparams, levels,
+                       luts, sdev, cnr, l3.S, l3.pitch, l3.plane, tiles_x);
 }
 
 void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& l3, const musica_hist_max_point* maxpts, int levels,

@@ -68,6 +68,9 @@ void launch_sqrt(hipStream_t st, const uint16_t* px, float* out, const LevelDesc
 void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch, int rows_per_wave);
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch);
 void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves, const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts);
+void launch_curves_cnr(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves,
+                       const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const float* sdev, float* cnr,
+                       const LevelDesc& l3);
 void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& l3, const musica_hist_max_point* maxpts, int levels, int batch);
 void launch_selftest_exact_math(hipStream_t st, unsigned long long* d_bad4);
 void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact,

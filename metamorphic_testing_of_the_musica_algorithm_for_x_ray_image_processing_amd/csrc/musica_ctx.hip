@@ -689,13 +689,10 @@ static void enqueue_dag(musica_ctx* c) {
     hipEventRecord(c->ev_join, c->side);
     c->cur = c->stream;
     hipStreamWaitEvent(c->stream, c->ev_join, 0);
-    {
+    {   // curves of every level + cnr of level 3 in one launch (kernels_analysis.hip k_curves_cnr)
         Span sp(c, MUSICA_KERNEL_CURVES);
-        launch_noise_curves(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts);
-    }
-    {
-        Span sp(c, MUSICA_KERNEL_CNR);
-        launch_cnr(c->stream, c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_noise_max, c->L, c->B);
+        launch_curves_cnr(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
+                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL]);
     }
     for (int lvl = MUSICA_CNR_LEVEL - 1; lvl >= 0; lvl--) {
         Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
@@ -739,13 +736,10 @@ static void enqueue_dag_levels(musica_ctx* c) {
         run_expand_level(c, lvl, c->rows_expand[lvl]);
     }
     for (int i = 0; i < MUSICA_CNR_LEVEL; i++) hipStreamWaitEvent(c->stream, c->ev_l[i], 0);
-    {
+    {   // curves of every level + cnr of level 3 in one launch (kernels_analysis.hip k_curves_cnr)
         Span sp(c, MUSICA_KERNEL_CURVES);
-        launch_noise_curves(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts);
-    }
-    {
-        Span sp(c, MUSICA_KERNEL_CNR);
-        launch_cnr(c->stream, c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_noise_max, c->L, c->B);
+        launch_curves_cnr(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
+                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL]);
     }
     for (int lvl = MUSICA_CNR_LEVEL - 1; lvl >= 0; lvl--) {
         Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
