@@ -235,22 +235,56 @@ __device__ __forceinline__ unsigned long long block_max_u64g(unsigned long long 
     return r;
 }
 
+// Several reductions behind one pair of barriers (the kernel is a chain of block-wide reductions: each pair of
+// barriers over 16 wavefronts costs about a microsecond of the step's critical path).
+__device__ __forceinline__ void block_max_sum_sum(unsigned long long& k, uint32_t& a, uint32_t& b, unsigned long long* s64, uint32_t* sa, uint32_t* sb) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long other = __shfl_xor(k, o);
+        k = other > k ? other : k;
+        a += (uint32_t)__shfl_xor((int)a, o);
+        b += (uint32_t)__shfl_xor((int)b, o);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) { s64[wv] = k; sa[wv] = a; sb[wv] = b; }
+    __syncthreads();
+    k = 0ull; a = 0u; b = 0u;
+    for (int i = 0; i < nw; i++) { k = s64[i] > k ? s64[i] : k; a += sa[i]; b += sb[i]; }
+    __syncthreads();
+}
+__device__ __forceinline__ void block_max_max(uint32_t& a, uint32_t& b, uint32_t* sa, uint32_t* sb) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a = max(a, (uint32_t)__shfl_xor((int)a, o));
+        b = max(b, (uint32_t)__shfl_xor((int)b, o));
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) { sa[wv] = a; sb[wv] = b; }
+    __syncthreads();
+    a = 0u; b = 0u;
+    for (int i = 0; i < nw; i++) { a = max(a, sa[i]); b = max(b, sb[i]); }
+    __syncthreads();
+}
+
 // One block of 1024 threads per image: thread i owns bin i.
 // gradation_curve_generate.comp:50-193. All integer arithmetic is uint32 and wraps, like GLSL's uint.
 __global__ __launch_bounds__(1024) void k_grad_curve(const uint32_t* __restrict__ hist, musica_hist_max_point* __restrict__ gmax,
                                                      DevCurve* __restrict__ curves) {
     __shared__ uint32_t cnt[MUSICA_GRAD_BINS];
-    __shared__ uint32_t s32[16];
+    __shared__ uint32_t s32[16], s32b[16];
     __shared__ unsigned long long s64[16];
     const int img = blockIdx.x;
     const uint32_t i = threadIdx.x;
     const uint32_t raw = hist[(size_t)img * MUSICA_GRAD_BINS + i];
     const uint32_t count = raw / 100u;                                           // :68
     cnt[i] = count;
-    // K12 on the raw histogram (src/vk_processing.cpp:2499): first maximum wins
+    // K12 on the raw histogram (src/vk_processing.cpp:2499, first maximum wins) and the two window sums, one pass
+    const uint32_t lowest = 10u;                                                 // :48
+    uint32_t meanCount = i >= lowest ? count * i : 0u;                           // :70 (wraps)
+    uint32_t meanSum = i >= lowest ? count : 0u;                                 // :71
     {
         unsigned long long k = raw ? (((unsigned long long)raw << 32) | (unsigned long long)(0xFFFFFFFFu - i)) : 0ull;
-        k = block_max_u64g(k, s64);
+        block_max_sum_sum(k, meanCount, meanSum, s64, s32, s32b);
         if (i == 0) {
             musica_hist_max_point mp;
             mp.maxValue = k ? (uint32_t)(k >> 32) : 0u;
@@ -258,9 +292,6 @@ __global__ __launch_bounds__(1024) void k_grad_curve(const uint32_t* __restrict_
             gmax[img] = mp;
         }
     }
-    const uint32_t lowest = 10u;                                                 // :48
-    const uint32_t meanCount = block_sum_u32(i >= lowest ? count * i : 0u, s32); // :70 (wraps)
-    const uint32_t meanSum = block_sum_u32(i >= lowest ? count : 0u, s32);       // :71
     const uint32_t meanQuot = meanSum ? meanCount / meanSum : 0u;                // :74 (x / 0 restated as 0)
     const float meanHistPos = (float)meanQuot / (float)MUSICA_GRAD_BINS;
     const uint32_t upper = f2u(meanHistPos * (float)MUSICA_GRAD_BINS);           // :77
@@ -272,17 +303,16 @@ __global__ __launch_bounds__(1024) void k_grad_curve(const uint32_t* __restrict_
     const uint32_t lowThreshold = f2u((float)maxCount * 0.05f);                  // :88
     // t0 (:94-105): walk down from maxPosition to 1 while count >= lowThreshold; t0 = lowest bin reached.
     // fail0 = highest bin in [1, maxPosition] violating the condition (0 if none).
-    unsigned long long f0 = (i >= 1 && i <= maxPosition && !(count >= lowThreshold)) ? (unsigned long long)i : 0ull;
-    f0 = block_max_u64g(f0, s64);
+    uint32_t f0 = (i >= 1 && i <= maxPosition && !(count >= lowThreshold)) ? i : 0u;
     // t1 (:108-119): walk up from maxPosition while count > 0; t1 = highest bin reached.
     // fail1 = lowest bin in [maxPosition, 1023] with count == 0 (1024 if none): max of (1024 - i).
-    unsigned long long f1 = (i >= maxPosition && count == 0u) ? (unsigned long long)(MUSICA_GRAD_BINS - i) : 0ull;
-    f1 = block_max_u64g(f1, s64);
+    uint32_t f1 = (i >= maxPosition && count == 0u) ? (uint32_t)MUSICA_GRAD_BINS - i : 0u;
+    block_max_max(f0, f1, s32, s32b);
     __shared__ float cx[kCurveCap], cy[kCurveCap];
     __shared__ int s_mono;
     // the window scalars are block-uniform: every thread derives them (same arithmetic as one thread would)
-    const uint32_t fail0 = (uint32_t)f0;
-    const uint32_t fail1 = f1 ? (uint32_t)(MUSICA_GRAD_BINS - f1) : (uint32_t)MUSICA_GRAD_BINS;
+    const uint32_t fail0 = f0;
+    const uint32_t fail1 = f1 ? (uint32_t)MUSICA_GRAD_BINS - f1 : (uint32_t)MUSICA_GRAD_BINS;
     float t0 = 0.0f, t1 = 0.0f;
     if (maxPosition >= 1u && fail0 < maxPosition) t0 = (float)(fail0 + 1u) * (1.0f / (float)MUSICA_GRAD_BINS);   // :96-100
     if (fail1 > maxPosition) t1 = (float)(fail1 - 1u) * (1.0f / (float)MUSICA_GRAD_BINS);                       // :110-115
