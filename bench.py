@@ -80,12 +80,15 @@ def main():
     ap.add_argument("--kernel-events", action="store_true",
                     help="bracket the metric kernel with HIP events inside the timed steps (forces eager launches: stream "
                          "capture drops event records, so the default timed region replays the hipGraph without events)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo + MUSICA_BENCH_ONE_DEVICE=1 rehearses the multi-rank flow on a one-GPU box (every rank on cuda:0, "
+                         "the stats rows travel through host memory)")
     ap.add_argument("--no-single-image", action="store_true", help="skip the one-image-per-execute measurement (keeps a kernel trace of the run pure)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel event passes after the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if os.environ.get("MUSICA_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
@@ -103,7 +106,10 @@ def main():
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n, levels, batch, bits, flags, desc = WORKLOADS[args.workload]
     if args.batch > 0:
@@ -150,7 +156,12 @@ def main():
     proc.stats_device(d_stats.data_ptr(), image_id_base=rank * batch)
     proc.sync()
     if distributed:
-        dist.all_gather_into_tensor(gathered, d_stats)            # RCCL over xGMI: the only inter-GPU traffic
+        if args.backend == "nccl":
+            dist.all_gather_into_tensor(gathered, d_stats)        # RCCL over xGMI: the only inter-GPU traffic
+        else:
+            parts = [torch.zeros((batch, stats_words), dtype=torch.int32) for _ in range(world)]
+            dist.all_gather(parts, d_stats.cpu())
+            gathered.copy_(torch.cat(parts).to("cuda"))
     else:
         gathered.copy_(d_stats)
     torch.cuda.synchronize()
@@ -159,7 +170,7 @@ def main():
 
     elapsed = t1 - t0
     if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     proc.profile_enable(False)

@@ -111,3 +111,28 @@ def test_process_shard_on_gpu_matches_oracle(ob):
         assert (g.t0, g.ta, g.t1, g.min_sqrt, g.max_sqrt) == (e.t0, e.ta, e.t1, e.min_sqrt, e.max_sqrt)
         assert abs(g.mean_cnr - e.mean_cnr) <= 1e-5 * max(1.0, abs(e.mean_cnr))
     proc.cleanup()
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_flow_on_one_device(tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed on a
+    one-GPU box: both ranks on cuda:0, gloo instead of RCCL for the stats gather. Checks the contract of the JSON
+    line (whole-job value, max-over-ranks time, one line from rank 0, rows of every rank gathered)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MUSICA_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo",
+           "--workload", "c1", "--no-kernel-events"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["config"]["stats_gathered"] == 2 * d["config"]["images_per_gpu_per_step"]
+    assert d["cpu_baseline"] is None and d["vs_baseline"] is None
+    mpix = 2 * d["config"]["images_per_gpu_per_step"] * d["config"]["image_size"] ** 2 * 4 / 1e6
+    assert abs(d["value"] - mpix / (d["ms_per_step"] * 4 / 1e3)) / d["value"] < 0.01
