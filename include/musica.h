@@ -129,7 +129,9 @@ typedef enum musica_image_kind {
     MUSICA_IMG_EXP_BANDPASS = 9, /* band after contrast curve (+ noise reduction on levels 0,1) as fed to img_addition; recomputed on demand */
     MUSICA_IMG_SQRT = 10,        /* sqrtImageState, N x N; recomputed on demand */
     MUSICA_IMG_CLAHE_GRADED = 11, /* claheGradedImageState, N x N (only with MUSICA_FLAG_CLAHE; src/vk_processing.cpp:432-438) */
-    MUSICA_IMG_KIND_COUNT = 12
+    MUSICA_IMG_CONTRAST_BAND = 12, /* expandBandpassImageStates[L-1-level]: band after the contrast curve, BEFORE noise reduction (what
+                                    * debugProcess dumps as exp_bandpass_i, src/vk_processing.cpp:2710-2718); recomputed on demand */
+    MUSICA_IMG_KIND_COUNT = 13
 } musica_image_kind;
 
 /* Pipeline stages runnable one at a time through musica_debug_run_stage
@@ -273,6 +275,19 @@ int musica_k_reduce(musica_ctx* ctx, const float* d_in, uint32_t side, uint32_t 
  * stream; returns mean microseconds per launch in *mean_us. */
 int musica_k_reduce_timed(musica_ctx* ctx, const float* d_in, uint32_t side, uint32_t in_pitch,
                           float* d_out, uint32_t out_pitch, uint32_t batch, uint32_t iters, double* mean_us);
+
+/* The same measurement from HBM rather than from the 256 MiB Infinity Cache: launch i uses input plane
+ * d_in + (i % nbuf) * in_pitch * side and output plane d_out + (i % nbuf) * out_pitch * ceil(side/2), so with
+ * nbuf * 5 * side^2 bytes well above 256 MiB no launch finds its input (or the lines of its output) on the die.
+ * rows_per_wave = 0 takes the library's own launch geometry (the one the pipeline uses). */
+int musica_k_reduce_timed_rot(musica_ctx* ctx, const float* d_in, uint32_t side, uint32_t in_pitch, float* d_out,
+                              uint32_t out_pitch, uint32_t nbuf, uint32_t iters, uint32_t rows_per_wave, double* mean_us);
+/* Measurement aid, not on the product path: a plain streaming kernel with the metric kernel's traffic shape
+ * (reads side^2 f32 with 16-byte loads, writes (side/2)^2 f32 with 16-byte stores, no halo, no arithmetic to
+ * speak of), timed the same rotating way — the ceiling `roofline.frac` can be read against. side % 8 == 0,
+ * dense rows. */
+int musica_k_copy41_timed_rot(musica_ctx* ctx, const float* d_in, uint32_t side, float* d_out, uint32_t nbuf,
+                              uint32_t iters, double* mean_us);
 
 /* Self-test of the exact arithmetic shortcuts that lean on a hardware approximation (v_rsq_f32) and therefore
  * cannot be checked on a CPU (csrc/exact_math.h): runs on the ctx device over EVERY float bit pattern and counts

@@ -42,6 +42,11 @@ def gather_rows(local_rows, world, dist=None, device=None):
         t = local_rows
     if world == 1 or dist is None:
         return t.clone()
+    if t.is_cuda and dist.get_backend() == "gloo":
+        # one-GPU rehearsal of the multi-rank flow (bench.py --backend gloo): the rows travel through host memory
+        parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]
+        dist.all_gather(parts, t.cpu().contiguous())
+        return torch.cat(parts).to(t.device)
     out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t.contiguous())
     return out

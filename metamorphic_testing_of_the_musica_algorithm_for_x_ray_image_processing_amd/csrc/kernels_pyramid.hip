@@ -22,7 +22,6 @@
 // Both forms evaluate exactly the oracle's MUSICA_ORDER_FAST arithmetic.
 #include "kernels_common.h"
 #include "launchers.h"
-#include "sdev_parts.h"
 
 namespace musica {
 
@@ -115,48 +114,10 @@ __device__ __forceinline__ void reduce_row(const RowR& r0, const RowR& r1, const
 }
 
 // grid: x = strips, y = ceil(segments / 4), z = batch. One wavefront = one (strip, segment).
-// T output rows per loop trip: the 2T new input rows (4T 16-byte loads per lane) are issued
-// back to back before any arithmetic, so a wavefront keeps 4T KiB in flight and the other
-// resident wavefronts of the SIMD cover its wait (no barrier, no LDS).
-template <int T>
-__global__ __launch_bounds__(kBlockThreads) void k_reduce_fast(const float* __restrict__ in, float* __restrict__ out,
-                                                               int S, int pitch, size_t in_plane, int So, int opitch,
-                                                               size_t out_plane, int rows_per_wave) {
-    const int lane = threadIdx.x & 63;
-    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
-    const int yo0 = seg * rows_per_wave;
-    if (yo0 >= So) return;  // wave-uniform
-    const int yo1 = min(yo0 + rows_per_wave, So);
-    const Buf ib = make_buf(in + (size_t)blockIdx.z * in_plane, in_plane * 4);
-    const Buf ob = make_buf(out + (size_t)blockIdx.z * out_plane, out_plane * 4);
-    const LaneCfg g = make_cfg(blockIdx.x, lane, S);
-    const int hi = S - 1;
-    const uint32_t rb = (uint32_t)pitch * 4u, orb = (uint32_t)opitch * 4u;
-
-    RowR w[2 * T + 3];  // input rows 2yo-2 .. 2yo+2T
-    load_row(w[0], ib, (uint32_t)mirror_idx(2 * yo0 - 2, hi) * rb, g);
-    load_row(w[1], ib, (uint32_t)mirror_idx(2 * yo0 - 1, hi) * rb, g);
-    load_row(w[2], ib, (uint32_t)(2 * yo0) * rb, g);
-    for (int yo = yo0; yo < yo1; yo += T) {
-#pragma unroll
-        for (int t = 0; t < T; t++) {
-            // rows past the segment are clamped onto valid rows: loaded, never consumed
-            const int ya = min(yo + t, yo1 - 1);
-            load_row(w[2 * t + 3], ib, (uint32_t)mirror_idx(2 * ya + 1, hi) * rb, g);
-            load_row(w[2 * t + 4], ib, (uint32_t)mirror_idx(2 * ya + 2, hi) * rb, g);
-        }
-#pragma unroll
-        for (int t = 0; t < T; t++) {
-            if (yo + t < yo1)  // wave-uniform
-                reduce_row(w[2 * t], w[2 * t + 1], w[2 * t + 2], w[2 * t + 3], w[2 * t + 4], g, ob, (uint32_t)(yo + t) * orb);
-        }
-        w[0] = w[2 * T]; w[1] = w[2 * T + 1]; w[2] = w[2 * T + 2];
-    }
-}
-
-// Software-pipelined form: one output row per trip, and the input rows of the next D trips are
-// already requested while trip k is computed, so a wavefront always has 2*D rows (4*D KiB) of loads in
-// flight behind its arithmetic (2*D more row registers than k_reduce_fast<1>).
+// Software-pipelined: one output row per trip, and the input rows of the next D trips are already
+// requested while trip k is computed, so a wavefront always has 2*D rows (4*D KiB) of loads in flight
+// behind its arithmetic. (Rows-per-trip, rotating-register and LDS-tiled forms of this kernel were
+// measured slower at 4096^2 in round 1 and live in the git history, not here.)
 // TAG only separates the launch sites in profiler output (one symbol per site, so rocprofv3's
 // per-kernel averages are not a mix of pyramid levels): 0 = level 0 of the pipeline, 1 = levels >= 1,
 // 2 = stand-alone musica_k_reduce, 3 = init-time autotune.
@@ -290,128 +251,6 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_u16_pf(const uint16_t*
         if (dir > 0) reduce_row(w0, w1, w2, w3, w4, g, ob, (uint32_t)yo * orb);  // wave-uniform
         else reduce_row(w4, w3, w2, w1, w0, g, ob, (uint32_t)yo * orb);
         w0 = w2; w1 = w3; w2 = w4;
-    }
-}
-
-// Rotating-register form of the pipelined kernel: the 5-row window plus the row pair in flight
-// occupy 7 register slots and the window advances by 2 slots per output row, so after 7 rows the
-// slot assignment repeats. The loop body is unrolled over that period with compile-time slot
-// indices: no register-to-register copies at all (k_reduce_fast_pf spends 77 v_mov per row on them).
-__global__ __launch_bounds__(kBlockThreads) void k_reduce_fast_rot(const float* __restrict__ in, float* __restrict__ out,
-                                                                   int S, int pitch, size_t in_plane, int So, int opitch,
-                                                                   size_t out_plane, int rows_per_wave) {
-    const int lane = threadIdx.x & 63;
-    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
-    const int yo0 = seg * rows_per_wave;
-    if (yo0 >= So) return;  // wave-uniform
-    const int yo1 = min(yo0 + rows_per_wave, So);
-    const Buf ib = make_buf(in + (size_t)blockIdx.z * in_plane, in_plane * 4);
-    const Buf ob = make_buf(out + (size_t)blockIdx.z * out_plane, out_plane * 4);
-    const LaneCfg g = make_cfg(blockIdx.x, lane, S);
-    const int hi = S - 1;
-    const uint32_t rb = (uint32_t)pitch * 4u, orb = (uint32_t)opitch * 4u;
-    RowR w[7];
-    load_row(w[0], ib, (uint32_t)mirror_idx(2 * yo0 - 2, hi) * rb, g);
-    load_row(w[1], ib, (uint32_t)mirror_idx(2 * yo0 - 1, hi) * rb, g);
-    load_row(w[2], ib, (uint32_t)(2 * yo0) * rb, g);
-    load_row(w[3], ib, (uint32_t)mirror_idx(2 * yo0 + 1, hi) * rb, g);
-    load_row(w[4], ib, (uint32_t)mirror_idx(2 * yo0 + 2, hi) * rb, g);
-    for (int yo = yo0; yo < yo1; yo += 7) {
-#pragma unroll
-        for (int ph = 0; ph < 7; ph++) {
-            if (yo + ph < yo1) {  // wave-uniform
-                constexpr int kSlots = 7;
-                const int base = (2 * ph) % kSlots;
-                const int yn = min(yo + ph + 1, yo1 - 1);  // the last row re-requests its own input (never consumed)
-                load_row(w[(base + 5) % kSlots], ib, (uint32_t)mirror_idx(2 * yn + 1, hi) * rb, g);
-                load_row(w[(base + 6) % kSlots], ib, (uint32_t)mirror_idx(2 * yn + 2, hi) * rb, g);
-                reduce_row(w[base], w[(base + 1) % kSlots], w[(base + 2) % kSlots], w[(base + 3) % kSlots], w[(base + 4) % kSlots], g, ob,
-                           (uint32_t)(yo + ph) * orb);
-            }
-        }
-    }
-}
-
-// LDS-tiled form of the same kernel (S % 8 == 0): a 256-thread workgroup produces a 64 x 16 output
-// tile from a (2*16+3) x (2*64+8) input tile staged in LDS. Every thread issues its 4-5 16-byte
-// global loads back to back, so a CU with 5 resident workgroups keeps ~95 KiB outstanding and
-// finished workgroups are replaced one by one. Vertical pass: LDS tile -> LDS v-buffer (16-byte
-// reads, four columns per thread); horizontal pass: three 16-byte LDS reads -> four outputs ->
-// one 16-byte global store. Reflect-101 columns are register selects in the horizontal pass;
-// mirrored rows are resolved when the tile is loaded. Same arithmetic order as k_reduce_fast.
-constexpr int kTileW = 64, kTileH = 16;
-constexpr int kTileCols = 2 * kTileW + 8;   // input columns 2*x0 - 4 .. 2*x0 + 131
-constexpr int kTileRows = 2 * kTileH + 3;   // input rows    2*y0 - 2 .. 2*y0 + 32
-constexpr int kTileGroups = kTileCols / 4;  // 16-byte groups per tile row
-
-__global__ __launch_bounds__(256) void k_reduce_tiled(const float* __restrict__ in, float* __restrict__ out, int S, int pitch,
-                                                      size_t in_plane, int So, int opitch, size_t out_plane) {
-    __shared__ __attribute__((aligned(16))) float tile[kTileRows][kTileCols];
-    __shared__ __attribute__((aligned(16))) float vbuf[kTileH][kTileCols];  // column index = tile column - 2
-    const int t = threadIdx.x;
-    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
-    const Buf ib = make_buf(in + (size_t)blockIdx.z * in_plane, in_plane * 4);
-    out += (size_t)blockIdx.z * out_plane;
-    const int hi = S - 1;
-    const int xin0 = 2 * x0 - 4;
-    // ---- stage the input tile -------------------------------------------------------------
-    constexpr int kSlots = kTileRows * kTileGroups;  // 35 * 34 = 1190
-    float4 ld[(kSlots + 255) / 256];
-#pragma unroll
-    for (int k = 0; k < (kSlots + 255) / 256; k++) {
-        const int slot = t + 256 * k;
-        const int r = slot / kTileGroups, g = slot - r * kTileGroups;
-        const int x = xin0 + 4 * g;
-        const int row = mirror_idx(min(2 * y0 - 2 + r, S + 1), hi);  // rows past the image feed unused outputs only
-        const uint32_t off = (slot < kSlots && x >= 0 && x < S) ? ((uint32_t)row * pitch + x) * 4u : kOob;
-        ld[k] = bload4(ib, off);
-    }
-#pragma unroll
-    for (int k = 0; k < (kSlots + 255) / 256; k++) {
-        const int slot = t + 256 * k;
-        const int r = slot / kTileGroups, g = slot - r * kTileGroups;
-        if (slot < kSlots) *reinterpret_cast<float4*>(&tile[r][4 * g]) = ld[k];
-    }
-    __syncthreads();
-    // ---- vertical pass: v(x, yo) = chain5 over tile rows 2*yo .. 2*yo + 4 ---------------------
-    constexpr int kVItems = kTileH * kTileGroups;  // 16 * 34 = 544
-#pragma unroll
-    for (int k = 0; k < (kVItems + 255) / 256; k++) {
-        const int item = t + 256 * k;
-        if (item < kVItems) {
-            const int yo = item / kTileGroups, g = item - yo * kTileGroups;
-            const float4 a = *reinterpret_cast<const float4*>(&tile[2 * yo][4 * g]);
-            const float4 b = *reinterpret_cast<const float4*>(&tile[2 * yo + 1][4 * g]);
-            const float4 c = *reinterpret_cast<const float4*>(&tile[2 * yo + 2][4 * g]);
-            const float4 d = *reinterpret_cast<const float4*>(&tile[2 * yo + 3][4 * g]);
-            const float4 e = *reinterpret_cast<const float4*>(&tile[2 * yo + 4][4 * g]);
-            const float v0 = chain5(a.x, b.x, c.x, d.x, e.x), v1 = chain5(a.y, b.y, c.y, d.y, e.y);
-            const float v2 = chain5(a.z, b.z, c.z, d.z, e.z), v3 = chain5(a.w, b.w, c.w, d.w, e.w);
-            // tile columns 4g .. 4g+3 land at v-buffer columns 4g-2 .. 4g+1 (two 8-byte stores)
-            if (g > 0) *reinterpret_cast<float2*>(&vbuf[yo][4 * g - 2]) = make_float2(v0, v1);
-            *reinterpret_cast<float2*>(&vbuf[yo][4 * g]) = make_float2(v2, v3);
-        }
-    }
-    __syncthreads();
-    // ---- horizontal pass: 4 outputs per thread --------------------------------------------------
-    const int yo = t >> 4, q = t & 15;
-    const int xo = x0 + 4 * q, yout = y0 + yo;
-    if (xo < So && yout < So) {
-        // v-buffer columns 8q .. 8q+11 hold input columns 2*xo - 2 .. 2*xo + 9
-        const float4 p0 = *reinterpret_cast<const float4*>(&vbuf[yo][8 * q]);
-        const float4 p1 = *reinterpret_cast<const float4*>(&vbuf[yo][8 * q + 4]);
-        const float4 p2 = *reinterpret_cast<const float4*>(&vbuf[yo][8 * q + 8]);
-        float m2 = p0.x, m1 = p0.y;                 // input columns 2*xo - 2, 2*xo - 1
-        const float c0 = p0.z, c1 = p0.w, c2 = p1.x, c3 = p1.y, c4 = p1.z, c5 = p1.w, c6 = p2.x, c7 = p2.y;
-        float c8 = p2.z;                            // input column 2*xo + 8
-        if (xo == 0) { m2 = c2; m1 = c1; }          // columns -2, -1 mirror onto 2, 1 (img_smooth.comp:13)
-        if (2 * xo + 8 >= S) c8 = c6;               // column S mirrors onto S - 2 (img_smooth.comp:12)
-        float4 o;
-        o.x = chain5(m2, m1, c0, c1, c2);
-        o.y = chain5(c0, c1, c2, c3, c4);
-        o.z = chain5(c2, c3, c4, c5, c6);
-        o.w = chain5(c4, c5, c6, c7, c8);
-        *reinterpret_cast<float4*>(out + (size_t)yout * opitch + xo) = o;
     }
 }
 
@@ -577,175 +416,6 @@ __global__ __launch_bounds__(kBlockThreads) void k_band_fast(const float* __rest
             }
         }
         cw[0] = cw[T]; cw[1] = cw[T + 1];
-    }
-}
-
-// ======================================================================================
-// K7 + K8 + K9 (+ K1 + K4 at level 0) + K10 + K11 in one march: band = fine - lowpass(coarse) is squared
-// while it is still in registers, so the 5x5 RMS and the noise histogram never re-read the band image
-// (-4 B per pixel and one launch less per level). A wavefront owns 512 columns x rows_per_wave coarse rows
-// (2 fine rows each; a multiple of 8 so that its fine rows start a 16-row histogram area) and additionally
-// computes — without storing it — the band of one row pair above and one below its segment and of two
-// columns left and right of its strip (on lane 0 / lane 63), which the 5x5 window of its own texels needs.
-// Every value is produced by the same expressions as in k_band_fast and k_sdev_hist_pf.
-// ======================================================================================
-struct CRowX {
-    CRow r;      // r.hl / r.hr hold the SAME value `near`: coarse column j0-1 on lane 0, j0+4 on lane 63
-    float far;   // coarse column j0-2 on lane 0, j0+5 on lane 63
-};
-struct XCfg {
-    uint32_t coff_x;   // byte offset of the coarse halo pair (j0-2, j0-1) on lane 0, (j0+4, j0+5) on lane 63, else kOob
-    uint32_t foff_x;   // byte offset (f32 rows) of the fine halo pair (c-2, c-1) on lane 0, (c+8, c+9) on lane 63, else kOob
-    bool edge_ok;      // this lane is lane 0 / lane 63 of a strip with a neighbour on that side
-};
-__device__ __forceinline__ XCfg make_xcfg(const LaneCfg& g) {
-    XCfg x;
-    const bool l = g.off_l != kOob, r = g.off_r != kOob;   // lane 0 with a left neighbour / lane 63 with a right one
-    x.edge_ok = l || r;
-    x.foff_x = l ? g.off_l : (r ? g.off_r : kOob);
-    x.coff_x = l ? g.coff_l - 4u : (r ? g.coff_r : kOob);
-    return x;
-}
-__device__ __forceinline__ void load_crowx(CRowX& w, const Buf& b, uint32_t row_off, const LaneCfg& g, const XCfg& x) {
-    const float4 a = bload4(b, g.coff + row_off);
-    w.r.v[0] = a.x; w.r.v[1] = a.y; w.r.v[2] = a.z; w.r.v[3] = a.w;
-    const float2 h = bload2(b, x.coff_x + row_off);
-    const float near = g.lane63 ? h.x : h.y;
-    w.r.hl = near; w.r.hr = near;
-    w.far = g.lane63 ? h.y : h.x;
-}
-// lowpass of the row pair for the lane's 8 columns (as lowpass_pair) and for its two halo columns:
-// A = the even one (c-2 or c+8), B = the odd one (c-1 or c+9).
-__device__ __forceinline__ void lowpass_pair_x(const CRowX& a, const CRowX& b, const CRowX& c, const LaneCfg& g,
-                                               float lowE[8], float lowO[8], float& lowEA, float& lowEB, float& lowOA, float& lowOB) {
-    float Ve[4], Vo[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        Ve[j] = chain_even(a.r.v[j], b.r.v[j], c.r.v[j]);
-        Vo[j] = chain_odd(b.r.v[j], c.r.v[j]);
-    }
-    const float Qe = chain_even(a.r.hl, b.r.hl, c.r.hl), Qo = chain_odd(b.r.hl, c.r.hl);   // near halo column
-    const float Fe = chain_even(a.far, b.far, c.far), Fo = chain_odd(b.far, c.far);          // far halo column
-    float l, r;
-    exchange(Ve, Qe, Qe, g, l, r);
-    hpass8(Ve, l, r, lowE);
-    exchange(Vo, Qo, Qo, g, l, r);
-    hpass8(Vo, l, r, lowO);
-    // lane 0: (P, Q, R) = (V[j0-2], V[j0-1], V[j0]); lane 63: (V[j0+3], V[j0+4], V[j0+5])
-    const float Pe = g.lane63 ? Ve[3] : Fe, Re = g.lane63 ? Fe : Ve[0];
-    const float Po = g.lane63 ? Vo[3] : Fo, Ro = g.lane63 ? Fo : Vo[0];
-    lowEA = 4.0f * chain_even(Pe, Qe, Re);
-    lowEB = 4.0f * chain_odd(Qe, Re);
-    lowOA = 4.0f * chain_even(Po, Qo, Ro);
-    lowOB = 4.0f * chain_odd(Qo, Ro);
-}
-__device__ __forceinline__ void square_band_row(SRow& r, const float b[8], float bA, float bB, const SCfg& sg, bool edge_ok) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const float t = j < sg.valid ? b[j] : 0.0f;
-        r.q[j] = t * t;
-    }
-    const float a = edge_ok ? bA : 0.0f, c = edge_ok ? bB : 0.0f;   // out of the image reads 0 (Q1)
-    r.l0 = a * a; r.l1 = c * c;
-    r.h0 = r.l0; r.h1 = r.l1;
-}
-__device__ __forceinline__ void zero_srow(SRow& r) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) r.q[j] = 0.0f;
-    r.l0 = r.l1 = r.h0 = r.h1 = 0.0f;
-}
-
-template <bool U16>
-__global__ __launch_bounds__(kBlockThreads) void k_band_sdev_fast(const float* __restrict__ fine, const float* __restrict__ coarse,
-                                                                  float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
-                                                                  size_t plane, int Sc, int cpitch, size_t cplane, int rows_per_wave,
-                                                                  const uint32_t* __restrict__ minmax, int min_chain_exact,
-                                                                  uint32_t* __restrict__ hist, size_t hist_stride, int cov) {
-    __shared__ uint32_t lh[MUSICA_NOISE_BINS + 64];
-    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS + 64; i += blockDim.x) lh[i] = 0u;
-    __syncthreads();
-    const int img = blockIdx.z;
-    const int lane = threadIdx.x & 63;
-    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
-    const int k0 = seg * rows_per_wave;
-    if (k0 < Sc) {
-        const int k1 = min(k0 + rows_per_wave, Sc);
-        NormK nk = make_norm(0.0f, 1.0f);
-        if (U16) {
-            float minv, maxv;
-            chain_scalars(minmax, img, min_chain_exact, minv, maxv);
-            nk = make_norm(minv, maxv);
-        }
-        const Buf fb = U16 ? make_buf(reinterpret_cast<const uint16_t*>(fine) + (size_t)img * S * S, (size_t)S * S * 2)
-                           : make_buf(fine + (size_t)img * plane, plane * 4);
-        const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
-        const Buf cb = make_buf(coarse + (size_t)img * cplane, cplane * 4);
-        float* srow0 = sdev + (size_t)img * plane;
-        const LaneCfg g = make_cfg(blockIdx.x, lane, S);
-        const SCfg sg = make_scfg(blockIdx.x, lane, S);
-        const XCfg xg = make_xcfg(g);
-        const uint32_t rb = (uint32_t)pitch * 4u, crb = (uint32_t)cpitch * 4u;
-        const uint32_t urb = (uint32_t)S * 2u;
-        const uint32_t uoff = g.off == kOob ? kOob : g.off >> 1, uoff_x = xg.foff_x == kOob ? kOob : xg.foff_x >> 1;
-
-        SRow w0, w1, w2, w3, w4;
-        zero_srow(w0); zero_srow(w1); zero_srow(w2); zero_srow(w3); zero_srow(w4);
-        bool alive[8] = {false, false, false, false, false, false, false, false};
-        const int ks = max(k0 - 1, 0);
-        CRowX ca, cm, cc;   // coarse rows km1(k), k, kp1(k)
-        load_crowx(ca, cb, (uint32_t)coarse_of_fine(2 * ks - 2, S) * crb, g, xg);
-        load_crowx(cm, cb, (uint32_t)ks * crb, g, xg);
-        // pairs k0-1 .. k1 (the first and the last only feed the 5x5 windows; outside the image they are zero rows)
-        for (int k = k0 - 1; k <= k1; k++) {
-            float be[8], bo[8], beA = 0.0f, beB = 0.0f, boA = 0.0f, boB = 0.0f;
-            const bool inside = k >= 0 && k < Sc;   // wave-uniform
-            if (inside) {
-                load_crowx(cc, cb, (uint32_t)coarse_of_fine(2 * k + 2, S) * crb, g, xg);
-                float feA, feB, foA, foB;
-                if (U16) {
-                    const float4 re = bload4(fb, uoff + (uint32_t)(2 * k) * urb), ro = bload4(fb, uoff + (uint32_t)(2 * k + 1) * urb);
-                    const uint32_t he = __float_as_uint(bload1(fb, uoff_x + (uint32_t)(2 * k) * urb));
-                    const uint32_t ho = __float_as_uint(bload1(fb, uoff_x + (uint32_t)(2 * k + 1) * urb));
-                    norm8(be, re, nk);
-                    norm8(bo, ro, nk);
-                    feA = norm_px(he & 0xFFFFu, nk); feB = norm_px(he >> 16, nk);
-                    foA = norm_px(ho & 0xFFFFu, nk); foB = norm_px(ho >> 16, nk);
-                } else {
-                    load8(be, fb, g.off + (uint32_t)(2 * k) * rb);
-                    load8(bo, fb, g.off + (uint32_t)(2 * k + 1) * rb);
-                    const float2 he = bload2(fb, xg.foff_x + (uint32_t)(2 * k) * rb), ho = bload2(fb, xg.foff_x + (uint32_t)(2 * k + 1) * rb);
-                    feA = he.x; feB = he.y; foA = ho.x; foB = ho.y;
-                }
-                float lowE[8], lowO[8], lEA, lEB, lOA, lOB;
-                lowpass_pair_x(ca, cm, cc, g, lowE, lowO, lEA, lEB, lOA, lOB);
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    be[j] = be[j] - lowE[j];   // img_difference.comp:15
-                    bo[j] = bo[j] - lowO[j];
-                }
-                beA = feA - lEA; beB = feB - lEB; boA = foA - lOA; boB = foB - lOB;
-                if (k >= k0 && k < k1) {
-                    store8(bb, g.off + (uint32_t)(2 * k) * rb, be);
-                    store8(bb, g.off + (uint32_t)(2 * k + 1) * rb, bo);
-                }
-                ca = cm; cm = cc;
-            }
-            // the two band rows enter the 5-row window of squares; each completes the window of the row two above it
-#pragma unroll
-            for (int ph = 0; ph < 2; ph++) {
-                w0 = w1; w1 = w2; w2 = w3; w3 = w4;
-                if (inside) square_band_row(w4, ph ? bo : be, ph ? boA : beA, ph ? boB : beB, sg, xg.edge_ok);
-                else zero_srow(w4);
-                const int y = 2 * k + ph - 2;
-                if (y >= 2 * k0 && y < 2 * k1) sdev_row<true>(w0, w1, w2, w3, w4, sg, S, y, cov, srow0 + (size_t)y * pitch, lh, alive);
-            }
-        }
-    }
-    __syncthreads();
-    uint32_t* gh = hist + (size_t)img * hist_stride;
-    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS; i += blockDim.x) {
-        const uint32_t v = lh[i];
-        if (v) atomicAdd(&gh[i], v);
     }
 }
 
@@ -1017,29 +687,13 @@ static const dim3 kGenericBlock(32, 8, 1);
 
 static inline bool fast_ok(int S) { return S >= 8 && (S % 8) == 0; }
 
-// rows_per_trip: 0 selects the LDS-tiled kernel, 1 / 2 / 4 the streaming kernel with that many rows per trip
+// tag: launch site (see k_reduce_fast_pf)
 void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch,
-                   int rows_per_wave, bool force_generic, int rows_per_trip, int tag) {
-    if (fast_ok(li.S) && !force_generic && rows_per_trip == 0) {
-        hipLaunchKernelGGL(k_reduce_tiled, dim3((lo.S + kTileW - 1) / kTileW, (lo.S + kTileH - 1) / kTileH, batch), dim3(256), 0, st, in, out,
-                           li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane);
-    } else if (fast_ok(li.S) && !force_generic) {
+                   int rows_per_wave, bool force_generic, int tag) {
+    if (fast_ok(li.S) && !force_generic) {
         const dim3 grid = stream_grid(li.S, lo.S, rows_per_wave, batch);
-        if (rows_per_trip <= -3)
-            hipLaunchKernelGGL(k_reduce_fast_rot, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
-        else if (rows_per_trip <= -2)
-            hipLaunchKernelGGL((k_reduce_fast_pf<2, 0>), grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
-        else if (rows_per_trip < 0)
-        {
-            auto* kern = tag == 0 ? k_reduce_fast_pf<1, 0> : tag == 1 ? k_reduce_fast_pf<1, 1> : tag == 2 ? k_reduce_fast_pf<1, 2> : k_reduce_fast_pf<1, 3>;
-            hipLaunchKernelGGL(kern, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
-        }
-        else if (rows_per_trip >= 4)
-            hipLaunchKernelGGL(k_reduce_fast<4>, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
-        else if (rows_per_trip >= 2)
-            hipLaunchKernelGGL(k_reduce_fast<2>, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
-        else
-            hipLaunchKernelGGL(k_reduce_fast<1>, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
+        auto* kern = tag == 0 ? k_reduce_fast_pf<1, 0> : tag == 1 ? k_reduce_fast_pf<1, 1> : tag == 2 ? k_reduce_fast_pf<1, 2> : k_reduce_fast_pf<1, 3>;
+        hipLaunchKernelGGL(kern, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
     } else {
         hipLaunchKernelGGL(k_reduce_generic, generic_grid(lo.S, batch), kGenericBlock, 0, st, in, out, li.S, li.pitch,
                            li.plane, lo.S, lo.pitch, lo.plane);
@@ -1060,20 +714,6 @@ void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, fl
         hipLaunchKernelGGL((k_band_fast<2, true>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
     else
         hipLaunchKernelGGL((k_band_fast<1, true>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
-}
-
-// fine: f32 planes, or the raw uint16 pixels when u16 is set (level 0). rows_per_wave: coarse rows, a multiple of 8.
-void launch_band_sdev(hipStream_t st, const void* fine, bool u16, const float* coarse, float* band, float* sdev, const LevelDesc& lf,
-                      const LevelDesc& lc, int batch, int rows_per_wave, const uint32_t* minmax, int min_chain_exact, uint32_t* hist,
-                      size_t hist_stride, int cov) {
-    const dim3 grid = stream_grid(lf.S, lc.S, rows_per_wave, batch);
-    const float* f = reinterpret_cast<const float*>(fine);
-    if (u16)
-        hipLaunchKernelGGL((k_band_sdev_fast<true>), grid, dim3(kBlockThreads), 0, st, f, coarse, band, sdev, lf.S, lf.pitch, lf.plane, lc.S,
-                           lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact, hist, hist_stride, cov);
-    else
-        hipLaunchKernelGGL((k_band_sdev_fast<false>), grid, dim3(kBlockThreads), 0, st, f, coarse, band, sdev, lf.S, lf.pitch, lf.plane, lc.S,
-                           lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact, hist, hist_stride, cov);
 }
 
 void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc,

@@ -48,15 +48,12 @@ struct GradArgs {
 };
 
 // kernels_pyramid.hip
-void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave, bool force_generic, int rows_per_trip, int tag);
+void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave, bool force_generic, int tag);
 void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave, bool force_generic, int rows_per_trip);
 void launch_reduce_u16(hipStream_t st, const uint16_t* px, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave,
                        const uint32_t* minmax, int min_chain_exact);
 void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                      int rows_per_wave, int rows_per_trip, const uint32_t* minmax, int min_chain_exact);
-void launch_band_sdev(hipStream_t st, const void* fine, bool u16, const float* coarse, float* band, float* sdev, const LevelDesc& lf,
-                      const LevelDesc& lc, int batch, int rows_per_wave, const uint32_t* minmax, int min_chain_exact, uint32_t* hist,
-                      size_t hist_stride, int cov);
 void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch);
 void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic, int rows_per_trip);
 void launch_exp_band(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch);
@@ -82,6 +79,8 @@ void launch_grad_hist_ref(hipStream_t st, const float* img, const float* relevan
 void launch_relevant(hipStream_t st, const float* normalized, const float* cnr, float* out, const LevelDesc& l0, const LevelDesc& l3, int cnrScale, int batch);
 void launch_grad_curve(hipStream_t st, const uint32_t* hist, musica_hist_max_point* gmax, DevCurve* curves, int batch);
 void launch_grad_apply(hipStream_t st, const float* in, float* out, const LevelDesc& l0, const DevCurve* curves, int batch);
+// kernels_bench.hip (measurement aid)
+void launch_copy41(hipStream_t st, const float* in, float* out, int side);
 // kernels_clahe.hip
 void launch_clahe(hipStream_t st, const float* img, const float* relevant, float* out, const LevelDesc& l0, uint32_t* hist, musica_point* pts, int batch);
 

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -31,6 +32,14 @@ static int fail(const char* fmt, ...) {
     fprintf(stderr, "MUSICA ERROR: %s\n", buf);  // cf. "VK STATE ERROR: %s" src/vk_processing.cpp:14-18
     return 0;
 }
+
+// No C++ exception may cross the extern "C" boundary (a ctypes / CLI caller would abort): entry points that allocate
+// host memory run their body under this guard and report through fail() like every other error.
+#define ABI_TRY try {
+#define ABI_CATCH(name_)                                                                             \
+    }                                                                                                \
+    catch (const std::exception& e_) { return fail("%s: %s", name_, e_.what()); }                   \
+    catch (...) { return fail("%s: unknown C++ exception", name_); }
 
 #define HIP_OK(call)                                                                       \
     do {                                                                                   \
@@ -96,10 +105,8 @@ struct musica_ctx {
     musica_nr_params h_nr[3];
     // rows each wavefront marches per launch, per level (heuristic, then autotuned at create)
     int rows_reduce[MUSICA_MAX_LEVELS], rows_band[MUSICA_MAX_LEVELS], rows_expand[MUSICA_MAX_LEVELS], rows_sdev[4];
-    int rows_bs[4];          // fused band + sdev kernel (coarse rows, multiples of 8)
-    bool fuse_bs;            // MUSICA_FUSE_BS=1: levels <= 3 with S >= 512, S % 8 == 0 run band and sdev as one kernel
     // tunables
-    int reduce_rows, band_rows, expand_rows, sdev_rows, grad_groups, reduce_trip, band_trip, expand_trip, min_waves;
+    int reduce_rows, band_rows, expand_rows, sdev_rows, grad_groups, band_trip, expand_trip, min_waves;
     // profiling
     uint32_t profiling;  // bit i set: bracket kernel family i with HIP events
     std::vector<ProfSpan> spans;
@@ -126,7 +133,7 @@ static bool dalloc(musica_ctx* c, T** out, size_t count) {
     void* p = nullptr;
     if (count == 0) count = 1;
     if (hipMalloc(&p, count * sizeof(T)) != hipSuccess) return false;
-    if (hipMemset(p, 0, count * sizeof(T)) != hipSuccess) return false;  // "never-written texels read as 0" (Q2)
+    if (hipMemset(p, 0, count * sizeof(T)) != hipSuccess) { hipFree(p); return false; }  // "never-written texels read as 0" (Q2)
     c->allocations.push_back(p);
     *out = (T*)p;
     return true;
@@ -213,7 +220,6 @@ static void copy_rows(musica_ctx* dst, const musica_ctx* src) {
     memcpy(dst->rows_band, src->rows_band, sizeof(src->rows_band));
     memcpy(dst->rows_expand, src->rows_expand, sizeof(src->rows_expand));
     memcpy(dst->rows_sdev, src->rows_sdev, sizeof(src->rows_sdev));
-    memcpy(dst->rows_bs, src->rows_bs, sizeof(src->rows_bs));
 }
 
 // Shallow copy of the parent restricted to images [i0, i0 + nb): same buffers, pointers moved to the first image.
@@ -261,7 +267,6 @@ static musica_ctx* make_view(const musica_ctx* c, int i0, int nb) {
         v->rows_band[i] = pick_rows(c->band_rows, 1, c->lv[i].S, c->lv[i + 1].S, nb);
         v->rows_expand[i] = pick_rows(c->expand_rows, 1, c->lv[i].S, c->lv[i + 1].S, nb);
         if (i <= MUSICA_CNR_LEVEL) v->rows_sdev[i] = pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, nb);
-        if (i <= MUSICA_CNR_LEVEL) v->rows_bs[i] = pick_rows(16, 8, c->lv[i].S, c->lv[i + 1].S, nb);
     }
     return v;
 }
@@ -321,7 +326,19 @@ void musica_destroy(musica_ctx* c) {
     delete c;
 }
 
+static musica_ctx* create_impl(const musica_params* params);
 musica_ctx* musica_create(const musica_params* params) {
+    try {
+        return create_impl(params);
+    } catch (const std::exception& e) {
+        fail("musica_create: %s", e.what());
+    } catch (...) {
+        fail("musica_create: unknown C++ exception");
+    }
+    return nullptr;
+}
+
+static musica_ctx* create_impl(const musica_params* params) {
     if (!params) { fail("musica_create: params is NULL"); return nullptr; }
     const uint32_t N = params->image_size;
     // 16384: a level-0 f32 plane is then 1 GiB — the kernels address planes through buffer descriptors with 32-bit
@@ -364,7 +381,6 @@ musica_ctx* musica_create(const musica_params* params) {
     for (int i = 0; i < c->L; i++) c->h_cparams[i] = host_contrast_params((uint32_t)i, L);
     for (int i = 0; i < 3; i++) c->h_nr[i] = host_nr_params((uint32_t)i);
     c->reduce_rows = env_int("MUSICA_REDUCE_ROWS", 16);
-    c->reduce_trip = env_int("MUSICA_REDUCE_TRIP", -1);
     c->band_trip = env_int("MUSICA_BAND_TRIP", 2);
     c->expand_trip = env_int("MUSICA_EXPAND_TRIP", 1);
     c->min_waves = env_int("MUSICA_MIN_WAVES", 2048);
@@ -391,10 +407,6 @@ musica_ctx* musica_create(const musica_params* params) {
     c->use_graph = c->dag && !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", 1) != 0;
     c->graph_exec = nullptr;
     c->graph_input = nullptr;
-    // Off by default: measured at 8 x 2048^2 the fused launch takes 116 us against 46 + 65 us for band and sdev apart —
-    // both are VALU-heavy after the exact sqrt / division work, so fusing them only adds up their instruction
-    // counts (151 VGPRs, 3 waves per SIMD) while the separate launches each overlap their arithmetic with HBM.
-    c->fuse_bs = env_int("MUSICA_FUSE_BS", 0) != 0;
     c->fuse_u16 = env_int("MUSICA_U16", 1) != 0 && (N % 8) == 0 && !(params->flags & MUSICA_FLAG_GENERIC_KERNELS);
     c->norm_valid = false;
     ok = ok && dalloc(c, &c->d_input, B * N * N);
@@ -438,7 +450,6 @@ musica_ctx* musica_create(const musica_params* params) {
         c->rows_band[i] = pick_rows(c->band_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
         c->rows_expand[i] = pick_rows(c->expand_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
         if (i <= MUSICA_CNR_LEVEL) c->rows_sdev[i] = pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, c->B);
-        if (i <= MUSICA_CNR_LEVEL) c->rows_bs[i] = pick_rows(16, 8, c->lv[i].S, c->lv[i + 1].S, c->B);
     }
     const bool tune = !(params->flags & MUSICA_FLAG_NO_AUTOTUNE) && env_int("MUSICA_AUTOTUNE", 1) && !c->generic;
     const int groups = pick_groups(c);
@@ -534,7 +545,7 @@ static void run_reduce_level(musica_ctx* c, int i, int rows) {
         launch_reduce_u16(c->cur, c->cur_input, c->lv[0], c->d_down[0], c->lv[1], c->B, rows, c->d_minmax, c->min_chain_exact);
         return;
     }
-    launch_reduce(c->cur, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, rows, c->generic, c->reduce_trip, c->tuning ? 3 : (i == 0 ? 0 : 1));
+    launch_reduce(c->cur, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, rows, c->generic, c->tuning ? 3 : (i == 0 ? 0 : 1));
 }
 static void run_band_level(musica_ctx* c, int i, int rows) {
     if (i == 0 && c->fuse_u16) {
@@ -542,16 +553,6 @@ static void run_band_level(musica_ctx* c, int i, int rows) {
         return;
     }
     launch_band(c->cur, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, rows, c->generic, c->band_trip);
-}
-static bool bs_fused_level(const musica_ctx* c, int i) {
-    return c->fuse_bs && !c->generic && i <= MUSICA_CNR_LEVEL && c->lv[i].S >= 512 && (c->lv[i].S % 8) == 0;
-}
-// band + sdev + noise histogram of level i in one launch
-static void run_band_sdev_level(musica_ctx* c, int i, int rows) {
-    const bool u16 = i == 0 && c->fuse_u16;
-    launch_band_sdev(c->cur, u16 ? (const void*)c->cur_input : (const void*)level_input(c, i), u16, c->d_down[i], c->d_band[i], c->d_sdev[i],
-                     c->lv[i], c->lv[i + 1], c->B, rows, c->d_minmax, c->min_chain_exact, c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS,
-                     (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov);
 }
 static void run_sdev_level(musica_ctx* c, int i, int rows) {
     launch_sdev_hist(c->cur, c->d_band[i], c->d_sdev[i], c->lv[i], c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS,
@@ -668,7 +669,6 @@ static void enqueue_dag(musica_ctx* c) {
     // kernels hold the wave slots either way) and CU-masked streams (32 / 224 CU split: 5 % slower).
     c->cur = c->stream;
     for (int i = 0; i < 2; i++) {
-        if (bs_fused_level(c, i)) { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_sdev_level(c, i, c->rows_bs[i]); continue; }
         { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
         { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
     }
@@ -678,7 +678,6 @@ static void enqueue_dag(musica_ctx* c) {
     c->cur = c->side;
     for (int i = 2; i < L; i++) {
         { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
-        if (bs_fused_level(c, i)) { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_band_sdev_level(c, i, c->rows_bs[i]); continue; }
         { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
         if (i <= MUSICA_CNR_LEVEL) { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
     }
@@ -719,11 +718,8 @@ static void enqueue_dag_levels(musica_ctx* c) {
         hipEventRecord(c->ev_r[i], c->stream);
         hipStreamWaitEvent(c->lvs[i], c->ev_r[i], 0);
         c->cur = c->lvs[i];
-        if (bs_fused_level(c, i)) { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_band_sdev_level(c, i, c->rows_bs[i]); }
-        else {
-            { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
-            if (i <= MUSICA_CNR_LEVEL) { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
-        }
+        { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
+        if (i <= MUSICA_CNR_LEVEL) { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
         hipEventRecord(c->ev_l[i], c->lvs[i]);
     }
     // the curve-free expand slots L-1 .. 3 follow the reduce chain on the main stream (idle until the curves anyway);
@@ -871,13 +867,11 @@ static void autotune(musica_ctx* c) {
     static const int cand_sdev[] = {16, 32, 64};
     for (int i = 0; i < c->L; i++) {
         if (c->lv[i].S < 512 || (c->lv[i].S % 8) != 0) continue;   // small levels are launch-bound: keep the heuristic
-        static const int cand_bs[] = {8, 16, 32};
-        struct { int* slot; const int* cand; int ncand; void (*fn)(musica_ctx*, int, int); bool use; } jobs[5] = {
-            {i <= MUSICA_CNR_LEVEL ? &c->rows_bs[i] : nullptr, cand_bs, 3, run_band_sdev_level, bs_fused_level(c, i)},
+        struct { int* slot; const int* cand; int ncand; void (*fn)(musica_ctx*, int, int); bool use; } jobs[4] = {
             {&c->rows_reduce[i], cand_reduce, 5, run_reduce_level, true},
-            {&c->rows_band[i], cand_pair, 4, run_band_level, !bs_fused_level(c, i)},
+            {&c->rows_band[i], cand_pair, 4, run_band_level, true},
             {&c->rows_expand[i], cand_pair, 4, run_expand_level, true},
-            {i <= MUSICA_CNR_LEVEL ? &c->rows_sdev[i] : nullptr, cand_sdev, 3, run_sdev_level, i <= MUSICA_CNR_LEVEL && !bs_fused_level(c, i)},
+            {i <= MUSICA_CNR_LEVEL ? &c->rows_sdev[i] : nullptr, cand_sdev, 3, run_sdev_level, i <= MUSICA_CNR_LEVEL},
         };
         for (auto& j : jobs) {
             if (!j.use) continue;
@@ -988,7 +982,7 @@ uint32_t musica_image_side(const musica_ctx* c, musica_image_kind kind, uint32_t
             return level == 0 ? (uint32_t)c->N : 0;
         case MUSICA_IMG_CNR: return level == MUSICA_CNR_LEVEL ? (uint32_t)c->lv[MUSICA_CNR_LEVEL].S : 0;
         case MUSICA_IMG_DOWNSAMPLED: return (int)level < c->L ? (uint32_t)c->lv[level + 1].S : 0;
-        case MUSICA_IMG_BANDPASS: case MUSICA_IMG_SDEV: case MUSICA_IMG_EXPAND: case MUSICA_IMG_LOWPASS: case MUSICA_IMG_EXP_BANDPASS:
+        case MUSICA_IMG_BANDPASS: case MUSICA_IMG_SDEV: case MUSICA_IMG_EXPAND: case MUSICA_IMG_LOWPASS: case MUSICA_IMG_EXP_BANDPASS: case MUSICA_IMG_CONTRAST_BAND:
             return (int)level < c->L ? (uint32_t)c->lv[level].S : 0;
         default: return 0;
     }
@@ -1025,9 +1019,9 @@ static int resolve_image(musica_ctx* c, uint32_t idx, musica_image_kind kind, ui
         case MUSICA_IMG_LOWPASS:  // lowpassImageStates[level] = smooth_upsampled(upsample(downsampled[level]))
             launch_lowpass(c->stream, c->d_down[level], c->d_scratch, c->lv[level], c->lv[level + 1], c->B);
             *plane = c->d_scratch + idx * c->lv[level].plane; *desc = &c->lv[level]; return 1;
-        case MUSICA_IMG_EXP_BANDPASS: {
+        case MUSICA_IMG_EXP_BANDPASS: case MUSICA_IMG_CONTRAST_BAND: {
             const ExpandArgs a = expand_args(c, (int)level, c->d_scratch);
-            launch_exp_band(c->stream, a, gain_mode((int)level), uses_nr((int)level), c->B);
+            launch_exp_band(c->stream, a, gain_mode((int)level), kind == MUSICA_IMG_EXP_BANDPASS && uses_nr((int)level), c->B);
             *plane = c->d_scratch + idx * c->lv[level].plane; *desc = &c->lv[level]; return 1;
         }
         default: return fail("musica_get_image: unsupported kind %d", (int)kind);
@@ -1077,6 +1071,7 @@ int musica_get_out_pixels(musica_ctx* c, uint32_t idx, uint8_t* dst) {
     if (!dst) return fail("musica_get_out_pixels: dst is NULL");
     const uint32_t N = (uint32_t)c->N, margin = MUSICA_OUT_MARGIN;
     if (N <= 2 * margin) return fail("musica_get_out_pixels: image too small for the %u-pixel margin", margin);
+    ABI_TRY
     std::vector<float> g((size_t)N * N);
     if (!download_plane(c, c->d_graded + (size_t)idx * c->lv[0].plane, c->lv[0], g.data())) return 0;
     const uint32_t nw = N - 2 * margin;
@@ -1087,16 +1082,20 @@ int musica_get_out_pixels(musica_ctx* c, uint32_t idx, uint8_t* dst) {
             dst[(size_t)y * nw + x] = (uint8_t)(int32_t)q;
         }
     return 1;
+    ABI_CATCH("musica_get_out_pixels")
 }
 
 int musica_save_out_image(musica_ctx* c, uint32_t idx, const char* path) {
     CHECK_CTX(c); CHECK_IMG(c, idx);
     if (!path) return fail("musica_save_out_image: path is NULL");
+    if ((uint32_t)c->N <= 2 * MUSICA_OUT_MARGIN) return fail("musica_save_out_image: image too small for the %u-pixel margin", (unsigned)MUSICA_OUT_MARGIN);
+    ABI_TRY
     const uint32_t nw = (uint32_t)c->N - 2 * MUSICA_OUT_MARGIN;
     std::vector<uint8_t> buf((size_t)nw * nw);
     if (!musica_get_out_pixels(c, idx, buf.data())) return 0;
     if (!musica_write_bmp_gray(path, nw, nw, buf.data())) return fail("failed to write out file");  // :2636-2642
     return 1;
+    ABI_CATCH("musica_save_out_image")
 }
 
 int musica_get_noise_hist(musica_ctx* c, uint32_t idx, uint32_t level, uint32_t* dst) {
@@ -1203,6 +1202,7 @@ static int dump_image(musica_ctx* c, uint32_t idx, musica_image_kind kind, uint3
 
 int musica_debug_process(musica_ctx* c, uint32_t idx, const char* dir) {
     CHECK_CTX(c); CHECK_IMG(c, idx);
+    ABI_TRY
     const std::string d = std::string(dir && *dir ? dir : ".") + "/";
     if (!dump_image(c, idx, MUSICA_IMG_NORMALIZED, 0, d + "norm.bmp", 1.0f, 0.0f)) return 0;               // :2664-2671
     for (int i = 0; i < c->L; i++) {                                                                       // :2673-2690
@@ -1213,7 +1213,8 @@ int musica_debug_process(musica_ctx* c, uint32_t idx, const char* dir) {
     if (!dump_image(c, idx, MUSICA_IMG_CNR, MUSICA_CNR_LEVEL, d + "cnr.bmp", 1.0f, 0.0f)) return 0;         // :2701-2708
     for (int i = 0; i < c->L; i++) {                                                                       // :2710-2727 (slot i <-> level L-1-i)
         const int lvl = c->L - 1 - i;
-        if (!dump_image(c, idx, MUSICA_IMG_EXP_BANDPASS, lvl, d + "exp_bandpass_" + std::to_string(i) + ".bmp", 1.0f, -1.0f)) return 0;
+        // expandBandpassImageStates[i]: the contrast-curve output, before noise reduction (src/vk_processing.cpp:1100)
+        if (!dump_image(c, idx, MUSICA_IMG_CONTRAST_BAND, lvl, d + "exp_bandpass_" + std::to_string(i) + ".bmp", 1.0f, -1.0f)) return 0;
         // expandLowpassImageStates[i] = smooth_upsampled(upsample(previous reconstruction))
         const LevelDesc& lf = c->lv[lvl];
         const float* prev = lvl == c->L - 1 ? c->d_down[c->L - 1] : c->d_recon[lvl + 1];
@@ -1259,6 +1260,7 @@ int musica_debug_process(musica_ctx* c, uint32_t idx, const char* dir) {
         fclose(f);
     }
     return 1;
+    ABI_CATCH("musica_debug_process")
 }
 
 // ---- profiling ------------------------------------------------------------------------
@@ -1300,7 +1302,7 @@ int musica_k_reduce(musica_ctx* c, const float* d_in, uint32_t side, uint32_t in
     CHECK_CTX(c);
     LevelDesc li, lo;
     if (!reduce_descs(side, in_pitch, out_pitch, &li, &lo)) return 0;
-    launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, pick_rows(c->reduce_rows, 1, li.S, lo.S, (int)batch), c->generic, c->reduce_trip, 2);
+    launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, pick_rows(c->reduce_rows, 1, li.S, lo.S, (int)batch), c->generic, 2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e));
     return 1;
@@ -1335,7 +1337,52 @@ int musica_k_reduce_timed(musica_ctx* c, const float* d_in, uint32_t side, uint3
     HIP_OK(hipEventCreate(&a));
     HIP_OK(hipEventCreate(&b));
     HIP_OK(hipEventRecord(a, c->stream));
-    for (uint32_t i = 0; i < iters; i++) launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, rpw, c->generic, c->reduce_trip, 2);
+    for (uint32_t i = 0; i < iters; i++) launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, rpw, c->generic, 2);
+    HIP_OK(hipEventRecord(b, c->stream));
+    HIP_OK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    if (mean_us) *mean_us = (double)ms * 1000.0 / (double)iters;
+    return 1;
+}
+
+int musica_k_reduce_timed_rot(musica_ctx* c, const float* d_in, uint32_t side, uint32_t in_pitch, float* d_out, uint32_t out_pitch, uint32_t nbuf,
+                              uint32_t iters, uint32_t rows_per_wave, double* mean_us) {
+    CHECK_CTX(c);
+    LevelDesc li, lo;
+    if (!reduce_descs(side, in_pitch, out_pitch, &li, &lo)) return 0;
+    if (iters < 1) iters = 1;
+    if (nbuf < 1) nbuf = 1;
+    const int rpw = rows_per_wave ? (int)rows_per_wave : pick_rows(c->reduce_rows, 1, li.S, lo.S, 1);
+    hipEvent_t a, b;
+    HIP_OK(hipEventCreate(&a));
+    HIP_OK(hipEventCreate(&b));
+    HIP_OK(hipEventRecord(a, c->stream));
+    for (uint32_t i = 0; i < iters; i++)
+        launch_reduce(c->stream, d_in + (size_t)(i % nbuf) * li.plane, li, d_out + (size_t)(i % nbuf) * lo.plane, lo, 1, rpw, c->generic, 2);
+    HIP_OK(hipEventRecord(b, c->stream));
+    HIP_OK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    if (mean_us) *mean_us = (double)ms * 1000.0 / (double)iters;
+    return 1;
+}
+
+int musica_k_copy41_timed_rot(musica_ctx* c, const float* d_in, uint32_t side, float* d_out, uint32_t nbuf, uint32_t iters, double* mean_us) {
+    CHECK_CTX(c);
+    if (side < 8 || (side & 7)) return fail("musica_k_copy41_timed_rot: side must be a multiple of 8");
+    if (iters < 1) iters = 1;
+    if (nbuf < 1) nbuf = 1;
+    const size_t in_plane = (size_t)side * side, out_plane = in_plane / 4;
+    hipEvent_t a, b;
+    HIP_OK(hipEventCreate(&a));
+    HIP_OK(hipEventCreate(&b));
+    HIP_OK(hipEventRecord(a, c->stream));
+    for (uint32_t i = 0; i < iters; i++) launch_copy41(c->stream, d_in + (size_t)(i % nbuf) * in_plane, d_out + (size_t)(i % nbuf) * out_plane, (int)side);
     HIP_OK(hipEventRecord(b, c->stream));
     HIP_OK(hipEventSynchronize(b));
     float ms = 0.f;

@@ -29,7 +29,7 @@ FLAG_NO_GRAPH = 0x2
 FLAG_GENERIC_KERNELS = 0x4
 
 IMG_NORMALIZED, IMG_DOWNSAMPLED, IMG_BANDPASS, IMG_SDEV, IMG_CNR, IMG_EXPAND = 0, 1, 2, 3, 4, 5
-IMG_GRADED, IMG_RELEVANT, IMG_LOWPASS, IMG_EXP_BANDPASS, IMG_SQRT, IMG_CLAHE_GRADED = 6, 7, 8, 9, 10, 11
+IMG_GRADED, IMG_RELEVANT, IMG_LOWPASS, IMG_EXP_BANDPASS, IMG_SQRT, IMG_CLAHE_GRADED, IMG_CONTRAST_BAND = 6, 7, 8, 9, 10, 11, 12
 STAGE_NORM, STAGE_REDUCE, STAGE_ANALYSIS, STAGE_EXPAND, STAGE_GRADATION = 0, 1, 2, 3, 4
 
 KERNEL_NAMES = ["minmax", "normalize", "reduce_l0", "reduce_rest", "band_l0", "band_rest", "sdev_hist", "curves",
@@ -82,7 +82,7 @@ class Stats(C.Structure):
     FLOAT_FIELDS = ("min_sqrt", "max_sqrt", "mean_cnr", "t0", "ta", "t1")
 
     def as_row(self):
-        """Fixed-size float64 row for the RCCL all-gather of the batch driver (13 values)."""
+        """The struct as a flat list of 14 floats (comparisons in tests; the gather itself moves the raw bytes)."""
         return [float(self.image_id), self.min_sqrt, self.max_sqrt] + [float(v) for v in self.noise_max_bin] + \
                [float(self.grad_max_bin), self.mean_cnr, self.t0, self.ta, self.t1, float(self.grad_max_value)]
 
@@ -130,6 +130,8 @@ ABI = {
     "musica_k_reduce": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32]),
     "musica_selftest_exact_math": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "musica_k_reduce_timed": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+    "musica_k_reduce_timed_rot": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+    "musica_k_copy41_timed_rot": (C.c_int, [_VP, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     "musica_device_alloc": (_VP, [_VP, C.c_size_t]),
     "musica_device_free": (None, [_VP, _VP]),
     "musica_memcpy_h2d": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
@@ -349,6 +351,10 @@ class MusicaProcessing:
         self._ok(self._lib.musica_get_clahe_curves(self._h, image_index, C.cast(out.ctypes.data, C.POINTER(Point))), "musica_get_clahe_curves")
         return out
 
+    def fuses_gradhist(self):
+        """True when the level-0 expand kernel also accumulates the gradation histogram (no separate k_grad_hist launch)."""
+        return False
+
     # ---- profiling ----------------------------------------------------------------------
     def profile_enable(self, which=True):
         """True: every kernel family; False: off; a list of kernel names: only those families."""
@@ -434,6 +440,28 @@ class MusicaProcessing:
             self.device_free(d_in)
             self.device_free(d_out)
         return us.value
+
+
+    def k_reduce_cold(self, side, nbuf=8, iters=64, rows_per_wave=0, copy_ceiling=True, seed=0):
+        """Mean microseconds per launch of the metric kernel on side x side f32 images rotating over `nbuf` distinct
+        input / output planes (nbuf * 5 * side^2 bytes must exceed the 256 MiB Infinity Cache for an HBM number),
+        and of the copy-shaped ceiling kernel timed the same way. Returns (kernel_us, copy_us or None)."""
+        so = side // 2
+        rng = np.random.default_rng(seed)
+        d_in, d_out = self.device_alloc(nbuf * side * side * 4), self.device_alloc(nbuf * so * so * 4)
+        try:
+            for k in range(nbuf):
+                self.h2d(d_in + k * side * side * 4, rng.random((side, side), dtype=np.float32))
+            us, cus = C.c_double(), C.c_double()
+            for it in (nbuf, iters):    # first pass: warm-up (code object, TLB)
+                self._ok(self._lib.musica_k_reduce_timed_rot(self._h, d_in, side, side, d_out, so, nbuf, it, rows_per_wave, C.byref(us)), "musica_k_reduce_timed_rot")
+            if copy_ceiling:
+                for it in (nbuf, iters):
+                    self._ok(self._lib.musica_k_copy41_timed_rot(self._h, d_in, side, d_out, nbuf, it, C.byref(cus)), "musica_k_copy41_timed_rot")
+        finally:
+            self.device_free(d_in)
+            self.device_free(d_out)
+        return us.value, (cus.value if copy_ceiling else None)
 
 
 def read_raw(path, image_size):

@@ -135,6 +135,8 @@ def lib():
     L.musica_oracle_out_pixels.argtypes = [vp, u8p]
     L.musica_oracle_save_out_image.restype = C.c_int
     L.musica_oracle_save_out_image.argtypes = [vp, C.c_char_p]
+    L.musica_oracle_debug_process.restype = C.c_int
+    L.musica_oracle_debug_process.argtypes = [vp, C.c_char_p]
     L.musica_oracle_write_bmp_gray.restype = C.c_int
     L.musica_oracle_write_bmp_gray.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, u8p]
     L.musica_oracle_read_raw.restype = C.c_int
@@ -277,6 +279,9 @@ class Oracle:
         out = np.empty((n, n), dtype=np.uint8)
         assert self.L.musica_oracle_out_pixels(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8))) == 1
         return out
+
+    def debug_process(self, directory):
+        assert self.L.musica_oracle_debug_process(self.h, os.fsencode(directory)) == 1
 
     def save_out_image(self, path):
         assert self.L.musica_oracle_save_out_image(self.h, os.fsencode(path)) == 1

@@ -889,7 +889,7 @@ static float* image_ptr(const musica_oracle* o, int kind, uint32_t level, uint32
         case MUSICA_ORACLE_IMG_UPSAMPLED: return o->upsampled[level];
         case MUSICA_ORACLE_IMG_EXP_UPSAMPLED: return o->exp_up[level];
         case MUSICA_ORACLE_IMG_EXP_LOWPASS: return o->exp_low[level];
-        case MUSICA_ORACLE_IMG_CONTRAST_BAND: return o->contrast_band[level];
+        case MUSICA_ORACLE_IMG_CONTRAST_BAND: case MUSICA_IMG_CONTRAST_BAND: return o->contrast_band[level];
         case MUSICA_ORACLE_IMG_NR_BAND: return level < 3 ? o->nr_band[level] : NULL;
         default: return NULL;
     }
@@ -987,6 +987,52 @@ int musica_oracle_save_out_image(const musica_oracle* o, const char* path) {
     uint8_t* buf = (uint8_t*)malloc((size_t)nw * nw);
     int ok = musica_oracle_out_pixels(o, buf) && musica_oracle_write_bmp_gray(path, nw, nw, buf);
     free(buf);
+    return ok;
+}
+
+/* VulkanState::downloadAndSaveImage, src/vk_state.cpp:809-855: every texel as (uint8_t)(255.0f * (v - min) / (max - min))
+ * (:834), written by stbi_write_bmp with one component (:848-854). The C cast is undefined outside [0, 256); restated as the
+ * x86 lowering the reference's MSVC build gets (cvttss2si to int32, low byte kept; NaN and out-of-int32 values give
+ * 0x80000000 -> 0) — the same statement as csrc/musica_ctx.hip dump_image. */
+static int dump_image(const float* img, uint32_t side, const char* dir, const char* name, float maxValue, float minValue) {
+    if (!img) return 0;
+    size_t n = (size_t)side * side;
+    uint8_t* out = (uint8_t*)malloc(n ? n : 1);
+    for (size_t i = 0; i < n; i++) {
+        float q = 255.0f * (img[i] - minValue) / (maxValue - minValue);
+        out[i] = (q == q && q > -2147483648.0f && q < 2147483648.0f) ? (uint8_t)(int32_t)q : 0;
+    }
+    char path[4096];
+    snprintf(path, sizeof(path), "%s/%s", dir && *dir ? dir : ".", name);
+    int ok = musica_oracle_write_bmp_gray(path, side, side, out);
+    free(out);
+    return ok;
+}
+
+/* VulkanProcessing::debugProcess, src/vk_processing.cpp:2661-2756: the image dumps, in the reference's order and with its
+ * (max, min) pairs. Slot i of the expand-side arrays is level L-1-i (src/vk_processing.cpp:930-934, 1099-1111);
+ * expandBandpassImageStates is the output of contrast_curve_apply (before noise reduction). The two RGBA plots
+ * (noise_hist.bmp, grad_hist.bmp, :2758-2806) come from render shaders that are out of scope. */
+int musica_oracle_debug_process(const musica_oracle* o, const char* dir) {
+    char name[64];
+    int ok = dump_image(o->normalized, o->N, dir, "norm.bmp", 1.0f, 0.0f);                          /* :2664-2671 */
+    for (uint32_t i = 0; i < o->L && ok; i++) {                                                       /* :2673-2690 */
+        snprintf(name, sizeof(name), "red_bandpass_%u.bmp", i);
+        ok = ok && dump_image(o->band[i], o->S[i], dir, name, 1.0f, -1.0f);
+        snprintf(name, sizeof(name), "red_lowpass_%u.bmp", i);
+        ok = ok && dump_image(o->lowpass[i], o->S[i], dir, name, 1.0f, 0.0f);
+    }
+    ok = ok && dump_image(o->sdev[MUSICA_CNR_LEVEL], o->S[MUSICA_CNR_LEVEL], dir, "sdev.bmp", 1.0f, -1.0f);   /* :2692-2699 */
+    ok = ok && dump_image(o->cnr, o->S[MUSICA_CNR_LEVEL], dir, "cnr.bmp", 1.0f, 0.0f);                        /* :2701-2708 */
+    for (uint32_t i = 0; i < o->L && ok; i++) {                                                       /* :2710-2727 */
+        uint32_t lvl = o->L - 1 - i;
+        snprintf(name, sizeof(name), "exp_bandpass_%u.bmp", i);
+        ok = ok && dump_image(o->contrast_band[lvl], o->S[lvl], dir, name, 1.0f, -1.0f);
+        snprintf(name, sizeof(name), "exp_lowpass_%u.bmp", i);
+        ok = ok && dump_image(o->exp_low[lvl], o->S[lvl], dir, name, 1.0f, 0.0f);
+    }
+    ok = ok && dump_image(o->relevant, o->N, dir, "relevant.bmp", 1.0f, 0.0f);                     /* :2729-2736 */
+    ok = ok && dump_image(o->graded, o->N, dir, "graded.bmp", 1.0f, 0.0f);                         /* :2749-2756 */
     return ok;
 }
 

@@ -87,6 +87,9 @@ const musica_point* musica_oracle_clahe_curves(const musica_oracle* o);
 /* saveOutImage restated (src/vk_processing.cpp:2603-2645): cropped 8-bit pixels, side N-20. */
 int musica_oracle_out_pixels(const musica_oracle* o, uint8_t* dst);
 int musica_oracle_save_out_image(const musica_oracle* o, const char* path);
+/* debugProcess (src/vk_processing.cpp:2661-2756): the image dumps norm / red_bandpass_i / red_lowpass_i / sdev / cnr /
+ * exp_bandpass_i / exp_lowpass_i / relevant / graded as 8-bit BMPs into `dir` (quantised as src/vk_state.cpp:834). */
+int musica_oracle_debug_process(const musica_oracle* o, const char* dir);
 /* stbi_write_bmp(path, w, h, 1, data) restated (stb_image_write.h:492-500). */
 int musica_oracle_write_bmp_gray(const char* path, uint32_t w, uint32_t h, const uint8_t* data);
 /* Raw reader of test/standalone/main.cpp:54-75. */

@@ -4,7 +4,7 @@ arrays. The reference ships no golden vectors for this path, so thes
 build's own oracle ("parity unpinned" still holds): they catch drift of the oracle between rounds, compiler /
 libm differences between the build container and the GPU box's CPU, and they give the HIP path a committed target.
 
-Run from the repo root:  python tests/golden/make_stage_fixtures.py
+Run from the repo root:  python tests/golden/make_stage_fixtures.py [--large]
 """
 import hashlib
 import json
@@ -21,6 +21,11 @@ from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.
 HERE = os.path.dirname(os.path.abspath(__file__))
 FULL = [(64, 4, 41, 0), (96, 5, 42, 0), (136, 0, 43, 1)]              # (N, levels, seed, flags): stored as arrays
 DIGEST = [(512, 4, 1, 0), (520, 5, 44, 0), (1024, 6, 7, 0), (512, 5, 45, 1)]   # stored as digests
+# BASELINE-sized cases (stage_digests_large.json; checked by the -m gpu tests only, where both the oracle and the HIP
+# path are held to them: the phantoms alone take minutes on the build container's CPU):
+#   configs[2] 4096^2 / L8 / CLAHE (rng(3)); the reference's own configuration 3072^2 / L = ceil(log2 N) = 12
+#   (test/standalone/main.cpp:31, src/vk_processing.cpp:1989); the 8 images of one configs[3] shard (C4: rng(100 + k)).
+LARGE = [(4096, 8, 3, 1), (3072, 0, 31, 0)] + [(2048, 6, 100 + k, 0) for k in range(8)]
 
 
 def stages(o, clahe):
@@ -72,6 +77,12 @@ def main():
         st = run(n, levels, seed, flags)
         dig["%d_L%d_s%d_f%d" % (n, levels, seed, flags)] = {k: digest(v) for k, v in st.items()}
     json.dump(dig, open(os.path.join(HERE, "stage_digests.json"), "w"), indent=1, sort_keys=True)
+    if "--large" in sys.argv:
+        dig = {}
+        for n, levels, seed, flags in LARGE:
+            st = run(n, levels, seed, flags)
+            dig["%d_L%d_s%d_f%d" % (n, levels, seed, flags)] = {k: digest(v) for k, v in st.items()}
+        json.dump(dig, open(os.path.join(HERE, "stage_digests_large.json"), "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -1,8 +1,8 @@
 """N > 1 path of the batch driver, rehearsed with world_size-2 gloo processes on CPU.
 
-The shard assignment and the statistics all-gather are exactly the code bench.py runs on GPUs; only the
-per-image compute is replaced here by the CPU oracle (test infrastructure), which fills the same
-`musica_stats` struct. Rendezvous on 127.0.0.1 (the container hostname may not resolve).
+The shard assignment (batch.assign_images) and the statistics all-gather (batch.gather_rows) are the functions
+bench.py calls on GPUs; only the per-image compute is replaced here by the CPU oracle (test infrastructure), which
+fills the same `musica_stats` struct. Rendezvous on 127.0.0.1 (the container hostname may not resolve).
 """
 import os
 import socket
@@ -113,26 +113,60 @@ def test_process_shard_on_gpu_matches_oracle(ob):
     proc.cleanup()
 
 
-@pytest.mark.gpu
-def test_bench_multi_rank_flow_on_one_device(tmp_path):
-    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed on a
-    one-GPU box: both ranks on cuda:0, gloo instead of RCCL for the stats gather. Checks the contract of the JSON
-    line (whole-job value, max-over-ranks time, one line from rank 0, rows of every rank gathered)."""
+def _check_bench_line(stdout, ranks, steps):
     import json
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["steps"] == steps and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["config"]["stats_gathered"] == ranks * d["config"]["images_per_gpu_per_step"] and d["config"]["ranks_joined"] == ranks
+    assert d["cpu_baseline"] is None and d["vs_baseline"] is None
+    mpix = ranks * d["config"]["images_per_gpu_per_step"] * d["config"]["image_size"] ** 2 * steps / 1e6
+    assert abs(d["value"] - mpix / (d["ms_per_step"] * steps / 1e3)) / d["value"] < 0.01
+    return d
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks_on_one_device():
+    """`python bench.py --gpus 2` started plainly (no launcher, no WORLD_SIZE): it must start two ranks itself, print
+    ONE line with n_gpus = 2 and the rows of both ranks gathered. Rehearsed on the one-GPU box: both ranks on cuda:0
+    (MUSICA_BENCH_ONE_DEVICE), gloo instead of RCCL for the stats gather."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MUSICA_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo",
+           "--workload", "C2", "--batch", "2", "--no-kernel-events", "--no-standalone", "--cpu-seconds", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check_bench_line(r.stdout, 2, 4)
+
+
+@pytest.mark.gpu
+def test_bench_under_an_external_launcher_and_rank_count_mismatch():
+    """The driver's form for N > 1 (torch.distributed.run starts the ranks), and the guard: a launcher that starts a
+    different number of ranks than --gpus asks for is an error, not a silently smaller job."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MUSICA_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo",
-           "--workload", "c1", "--no-kernel-events"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(_free_port()), os.path.join(root, "bench.py")]
+    tail = ["--steps", "4", "--warmup", "1", "--backend", "gloo", "--workload", "C2", "--no-kernel-events", "--no-standalone", "--cpu-seconds", "0"]
+    r = subprocess.run(base + ["--gpus", "2"] + tail, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
-    assert d["config"]["stats_gathered"] == 2 * d["config"]["images_per_gpu_per_step"]
-    assert d["cpu_baseline"] is None and d["vs_baseline"] is None
-    mpix = 2 * d["config"]["images_per_gpu_per_step"] * d["config"]["image_size"] ** 2 * 4 / 1e6
-    assert abs(d["value"] - mpix / (d["ms_per_step"] * 4 / 1e3)) / d["value"] < 0.01
+    _check_bench_line(r.stdout, 2, 4)
+    base[base.index("--master-port") + 1] = str(_free_port())
+    r = subprocess.run(base + ["--gpus", "4"] + tail, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE (2) != --gpus (4)" in (r.stderr + r.stdout)
+
+
+def test_bench_rank_mismatch_is_refused_without_a_gpu():
+    """The same guard needs no GPU: it fires before torch is imported."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=120, cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE (2) != --gpus (8)" in r.stderr

@@ -167,20 +167,6 @@ def test_image_groups_give_the_same_bits(ob, flags, monkeypatch):
     grp.cleanup()
 
 
-@pytest.mark.parametrize("n,levels,batch", [(1024, 6, 1), (2048, 6, 2), (1544, 0, 1)])
-def test_fused_band_sdev_kernel_gives_the_same_bits(ob, n, levels, batch, monkeypatch):
-    """MUSICA_FUSE_BS=1: band, 5x5 RMS and noise histogram of the large levels in one launch (k_band_sdev_fast,
-    raw uint16 input at level 0) against the oracle; several strips, partial last strip (1544 = 3 x 512 + 8)."""
-    monkeypatch.setenv("MUSICA_FUSE_BS", "1")
-    px = np.stack([phantom(n, 700 + k) for k in range(batch)])
-    p = _proc(n, levels, batch=batch)
-    assert p.execute(px)
-    for k in range(batch):
-        o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[k])
-        _compare_all(p, o, ob, idx=k, tag="fused image %d: " % k)
-    p.cleanup()
-
-
 @pytest.mark.parametrize("batch", [1, 3])
 def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
     """MUSICA_DAG = 0 (one in-order stream, the reference's order), 1 (two streams), 2 (one stream per level),
@@ -199,15 +185,13 @@ def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
             p.cleanup()
 
 
-@pytest.mark.parametrize("env", [{"MUSICA_REDUCE_TRIP": "0"}, {"MUSICA_REDUCE_TRIP": "1"}, {"MUSICA_REDUCE_TRIP": "2"},
-                                 {"MUSICA_REDUCE_TRIP": "4"}, {"MUSICA_REDUCE_TRIP": "-2"}, {"MUSICA_REDUCE_TRIP": "-3"},
-                                 {"MUSICA_BAND_TRIP": "1"}, {"MUSICA_EXPAND_TRIP": "2"}, {"MUSICA_U16": "0"},
+@pytest.mark.parametrize("env", [{"MUSICA_BAND_TRIP": "1"}, {"MUSICA_EXPAND_TRIP": "2"}, {"MUSICA_U16": "0"},
                                  {"MUSICA_AUTOTUNE": "0", "MUSICA_REDUCE_ROWS": "4", "MUSICA_BAND_ROWS": "2", "MUSICA_EXPAND_ROWS": "2", "MUSICA_SDEV_ROWS": "16"},
                                  {"MUSICA_AUTOTUNE": "0", "MUSICA_REDUCE_ROWS": "32", "MUSICA_BAND_ROWS": "16", "MUSICA_EXPAND_ROWS": "16", "MUSICA_SDEV_ROWS": "64", "MUSICA_MIN_WAVES": "1"}],
                          ids=lambda e: ",".join("%s=%s" % (k[7:], v) for k, v in e.items()))
 def test_kernel_variants_and_launch_geometries_give_the_same_bits(ob, env, monkeypatch):
-    """The alternative forms of the streaming kernels kept in the library (LDS-tiled, rows-per-trip, rotating
-    registers, stored normalized image) and extreme rows-per-wavefront choices: all bit-identical to the oracle."""
+    """The alternative forms of the streaming kernels kept in the library (rows-per-trip of band / expand, stored
+    normalized image) and extreme rows-per-wavefront choices: all bit-identical to the oracle."""
     n, levels = 1024, 6
     px = phantom(n, 900)
     o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px)
@@ -398,8 +382,15 @@ def test_metric_kernel_properties_full_size():
     p.cleanup()
 
 
-@pytest.mark.parametrize("n,levels,seed", [(512, 4, 1), (1024, 6, 7)])
+@pytest.mark.parametrize("n,levels,seed", [(512, 4, 1), (1024, 6, 7), (2048, 6, 100)])
 def test_pipeline_close_to_literal_oracle(ob, n, levels, seed):
+    """HIP (separable order) against the oracle in the shaders' LITERAL 25-tap order: this is the tolerance the
+    build claims against the reference's arithmetic (parity with the reference itself is unpinned). Stencil
+    outputs within 4e-7 / 1e-6; histogram argmax within one bin. The end of the pipeline is then bounded in BOTH
+    situations: when every noise-histogram argmax agrees (the contrast curves are then identical) the
+    reconstruction is within 4e-6 and at most 0.1 % of the 8-bit pixels differ; when an argmax moved by one bin
+    (a tie broken by 1e-7-level differences: p changes by 1 / 2048 * 0.1, the curve abscissae with it) the
+    reconstruction is within 2e-3 and the 8-bit image within one grey level on 99 % of the pixels."""
     px = phantom(n, seed)
     o = ob.Oracle(n, levels, ob.ORDER_REFERENCE).execute(px)
     p = _proc(n, levels)
@@ -408,14 +399,21 @@ def test_pipeline_close_to_literal_oracle(ob, n, levels, seed):
     for i in range(o.levels):
         assert np.abs(p.image(mp.IMG_DOWNSAMPLED, i) - o.image(ob.IMG_DOWNSAMPLED, i)).max() <= 4e-7
         assert np.abs(p.image(mp.IMG_BANDPASS, i) - o.image(ob.IMG_BANDPASS, i)).max() <= 1e-6
+    shifts = []
     for i in range(4):
         assert np.abs(p.image(mp.IMG_SDEV, i) - o.image(ob.IMG_SDEV, i)).max() <= 1e-6
-        assert abs(p.noise_hist_max(i)[1] - o.noise_hist_max(i)[1]) <= 1
+        shifts.append(abs(int(p.noise_hist_max(i)[1]) - int(o.noise_hist_max(i)[1])))
+        assert shifts[-1] <= 1
         assert np.abs(p.noise_hist(i).astype(np.int64) - o.noise_hist(i).astype(np.int64)).sum() <= 0.01 * o.noise_hist(i).sum() + 4
-    if all(p.noise_hist_max(i)[1] == o.noise_hist_max(i)[1] for i in range(4)):
-        assert np.abs(p.image(mp.IMG_EXPAND, 0) - o.image(ob.IMG_EXPAND, 0)).max() <= 4e-6
-        diff = p.out_pixels().astype(np.int32) != o.out_pixels().astype(np.int32)
-        assert diff.mean() <= 1e-3
+    rec = np.abs(p.image(mp.IMG_EXPAND, 0) - o.image(ob.IMG_EXPAND, 0)).max()
+    d8 = np.abs(p.out_pixels().astype(np.int32) - o.out_pixels().astype(np.int32))
+    if max(shifts) == 0:
+        assert rec <= 4e-6
+        assert (d8 != 0).mean() <= 1e-3
+    else:
+        print("noise-histogram argmax shifted by one bin at levels", [i for i in range(4) if shifts[i]])
+        assert rec <= 2e-3
+        assert (d8 > 1).mean() <= 1e-2
     p.cleanup()
 
 
@@ -497,17 +495,35 @@ def test_save_out_image_and_debug_process(ob, tmp_path):
     o.save_out_image(str(b))
     assert a.read_bytes() == b.read_bytes()
     assert len(a.read_bytes()) == 54 + (n - 20) * ((n - 20) * 3)
-    d = tmp_path / "dump"
+    # debugProcess (src/vk_processing.cpp:2661-2756): every image dump byte for byte against the oracle's restatement
+    # of the same function (quantisation of src/vk_state.cpp:834, one-component stbi_write_bmp)
+    d, e = tmp_path / "dump", tmp_path / "oracle_dump"
     d.mkdir()
+    e.mkdir()
     assert p.debugProcess(str(d))
+    o.debug_process(str(e))
+    images = ["norm.bmp", "sdev.bmp", "cnr.bmp", "relevant.bmp", "graded.bmp"] + \
+             ["red_bandpass_%d.bmp" % i for i in range(levels)] + ["red_lowpass_%d.bmp" % i for i in range(levels)] + \
+             ["exp_bandpass_%d.bmp" % i for i in range(levels)] + ["exp_lowpass_%d.bmp" % i for i in range(levels)]
+    assert sorted(f.name for f in e.iterdir()) == sorted(images)
     names = {f.name for f in d.iterdir()}
-    for want in ["norm.bmp", "sdev.bmp", "cnr.bmp", "relevant.bmp", "graded.bmp", "noise_hist.csv", "grad_hist.csv", "grad_curve.csv"] + \
-                ["red_bandpass_%d.bmp" % i for i in range(levels)] + ["red_lowpass_%d.bmp" % i for i in range(levels)] + \
-                ["exp_bandpass_%d.bmp" % i for i in range(levels)] + ["exp_lowpass_%d.bmp" % i for i in range(levels)]:
+    for want in images + ["noise_hist.csv", "grad_hist.csv", "grad_curve.csv"]:
         assert want in names, want
-    # graded.bmp is the un-cropped 8-bit image (VulkanState::downloadAndSaveImage, src/vk_state.cpp:809-855)
+    for name in images:
+        assert (d / name).read_bytes() == (e / name).read_bytes(), name
+    # graded.bmp is the un-cropped 8-bit image; the level-3 dumps have side N / 8
     raw = (d / "graded.bmp").read_bytes()
     assert int.from_bytes(raw[18:22], "little") == n
+    assert int.from_bytes((d / "cnr.bmp").read_bytes()[18:22], "little") == n // 8
+    # exp_bandpass_i is the contrast-curve output of level L-1-i BEFORE noise reduction (expandBandpassImageStates, :1100)
+    _same(p.image(mp.IMG_CONTRAST_BAND, 0), o.image(ob.IMG_CONTRAST_BAND, 0), "contrast band 0")
+    assert not np.array_equal(p.image(mp.IMG_CONTRAST_BAND, 0), p.image(mp.IMG_EXP_BANDPASS, 0))
+    # the CSVs hold the histograms / curve the getters return
+    rows = (d / "grad_hist.csv").read_text().splitlines()
+    assert rows[0] == "bin,weight" and [int(r.split(",")[1]) for r in rows[1:]] == [int(v) for v in o.grad_hist()]
+    rows = (d / "noise_hist.csv").read_text().splitlines()[1:]
+    for lvl in range(4):
+        assert [int(r.split(",")[1 + lvl]) for r in rows] == [int(v) for v in o.noise_hist(lvl)]
     p.cleanup()
 
 
