@@ -372,31 +372,36 @@ __device__ __forceinline__ void noise_curves_block(int level, int img, const uin
     curve_store_parallel(c, cx, cy, &s_mono, npts, 0.0f, 0.0f, 0.0f);
     if (level >= MUSICA_COARSER_LEVELS_START) return;   // only the 33-point curves get a lookup table (block-uniform)
     __syncthreads();
-    // ---- bucket table for the expand kernel (see DevCurveLut) ----
+    // ---- lookup tables for the expand kernel (see DevCurveLut) ----
     DevCurveLut* lut = luts + (size_t)img * MUSICA_COARSER_LEVELS_START + level;
     const int count = npts;
     const float range = cx[kLutTailFirst - 1] * 1.25f;                // 1.75 p: above x[22] = 1.4 p, below x[23] >= 1.49 p + 0.01
     const float inv_w = (float)kLutBuckets / range;
-    if (threadIdx.x == 0) sok = (s_mono && count == 33 && range > 0.0f && inv_w < 3.0e38f) ? 1 : 0;
+    __shared__ int scoarse[kCurveCap];
+    if (threadIdx.x == 0) sok = (s_mono && count == kLutPoints && range > 0.0f && inv_w < 3.0e38f && cx[0] == 0.0f) ? 1 : 0;
     if ((int)threadIdx.x < kCurveCap) {
         const float x = cx[threadIdx.x];
         sx[threadIdx.x] = x;
-        const float kf = x * inv_w;
+        const float kf = x * inv_w;                                    // the expand kernel's expression for the fine bucket
         sbucket[threadIdx.x] = ((int)threadIdx.x < count && kf < (float)kLutBuckets) ? (int)kf : kLutBuckets;
+        const float cf = fminf(x * 256.0f, (float)(kLutCoarse - 1));  // ... and for the coarse bucket
+        scoarse[threadIdx.x] = (int)cf;
     }
     __syncthreads();
-    if ((int)threadIdx.x < count) {   // the table covers exactly the abscissae 0..22
+    if ((int)threadIdx.x < count) {   // the fine table covers exactly the abscissae 0..22
         const bool inside = sbucket[threadIdx.x] < kLutBuckets;
         if (inside != ((int)threadIdx.x < kLutTailFirst)) sok = 0;
     }
-    {
-        const int k = threadIdx.x;    // one thread per bucket (blockDim.x == kLutBuckets)
-        int jlo = 0, inb = 0;
+    for (int k = threadIdx.x; k < kLutBuckets + kLutCoarse; k += blockDim.x) {
+        const bool fine = k < kLutBuckets;
+        const int kb = fine ? k : k - kLutBuckets;
+        const int first = fine ? 0 : kLutTailFirst;                     // the coarse table only ever sees s above x[0..22]
+        int jlo = first, inb = 0;
         float xa = __builtin_huge_valf(), xb = __builtin_huge_valf();
-        for (int i = 0; i < count && i < kCurveCap; i++) {
-            const int b = sbucket[i];
-            if (b < k) jlo++;
-            else if (b == k) {
+        for (int i = first; i < count && i < kCurveCap; i++) {
+            const int b = fine ? sbucket[i] : scoarse[i];
+            if (b < kb) jlo++;
+            else if (b == kb) {
                 if (inb == 0) xa = sx[i];
                 else if (inb == 1) xb = sx[i];
                 inb++;
@@ -404,6 +409,13 @@ __device__ __forceinline__ void noise_curves_block(int level, int img, const uin
         }
         if (inb > 2) sok = 0;
         lut->bucket[k] = make_float4((float)jlo, xa, xb, 0.0f);
+    }
+    if ((int)threadIdx.x <= kLutPoints) {   // segment table: same slopes as DevCurve::m (linearFunction, contrast_curve_apply.comp:22-25)
+        const int j = threadIdx.x;
+        float4 sg = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (j == 0) sg = make_float4(cx[0], cy[0], 0.0f, 0.0f);
+        else if (j < count) sg = make_float4(cx[j - 1], cy[j - 1], (cy[j] - cy[j - 1]) / (cx[j] - cx[j - 1]), 0.0f);
+        lut->seg[j] = sg;
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -20,6 +20,7 @@
 // one thread per output texel with the shaders' mirror()/out-of-bounds rules applied per tap.
 //
 // Both forms evaluate exactly the oracle's MUSICA_ORDER_FAST arithmetic.
+#include <stdlib.h>
 #include "kernels_common.h"
 #include "launchers.h"
 
@@ -70,8 +71,9 @@ struct RowR {
     float hr;        // column c0+512 of the strip (lane 63 only)
 };
 
+template <int AUX = 0>
 __device__ __forceinline__ void load8(float d[8], const Buf& b, uint32_t off) {
-    const float4 a = bload4(b, off), c = bload4(b, off + 16u);
+    const float4 a = bload4_aux<AUX>(b, off), c = bload4_aux<AUX>(b, off + 16u);
     d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = c.x; d[5] = c.y; d[6] = c.z; d[7] = c.w;
 }
 __device__ __forceinline__ void store8(const Buf& b, uint32_t off, const float d[8]) {
@@ -79,8 +81,9 @@ __device__ __forceinline__ void store8(const Buf& b, uint32_t off, const float d
     bstore4(b, off + 16u, make_float4(d[4], d[5], d[6], d[7]));
 }
 
+template <int AUX = 0>
 __device__ __forceinline__ void load_row(RowR& r, const Buf& b, uint32_t row_off, const LaneCfg& g) {
-    load8(r.v, b, g.off + row_off);
+    load8<AUX>(r.v, b, g.off + row_off);
     const float2 h = bload2(b, g.off_l + row_off);
     r.hl0 = h.x; r.hl1 = h.y;
     r.hr = bload1(b, g.off_r + row_off);
@@ -120,8 +123,8 @@ __device__ __forceinline__ void reduce_row(const RowR& r0, const RowR& r1, const
 // measured slower at 4096^2 in round 1 and live in the git history, not here.)
 // TAG only separates the launch sites in profiler output (one symbol per site, so rocprofv3's
 // per-kernel averages are not a mix of pyramid levels): 0 = level 0 of the pipeline, 1 = levels >= 1,
-// 2 = stand-alone musica_k_reduce, 3 = init-time autotune.
-template <int D, int TAG>
+// 2 = stand-alone musica_k_reduce, 3 = init-time autotune, 4 = stand-alone rotating over distinct planes (musica_k_reduce_timed_rot).
+template <int D, int TAG, int AUX = 0>
 __global__ __launch_bounds__(kBlockThreads) void k_reduce_fast_pf(const float* __restrict__ in, float* __restrict__ out,
                                                                   int S, int pitch, size_t in_plane, int So, int opitch,
                                                                   size_t out_plane, int rows_per_wave) {
@@ -143,20 +146,20 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_fast_pf(const float* _
     const int n = yo1 - yo0;
     const int yfirst = dir > 0 ? yo0 : yo1 - 1;
     RowR w[5 + 2 * D];
-    load_row(w[0], ib, (uint32_t)mirror_idx(2 * yfirst - 2 * dir, hi) * rb, g);
-    load_row(w[1], ib, (uint32_t)mirror_idx(2 * yfirst - dir, hi) * rb, g);
-    load_row(w[2], ib, (uint32_t)(2 * yfirst) * rb, g);
+    load_row<AUX>(w[0], ib, (uint32_t)mirror_idx(2 * yfirst - 2 * dir, hi) * rb, g);
+    load_row<AUX>(w[1], ib, (uint32_t)mirror_idx(2 * yfirst - dir, hi) * rb, g);
+    load_row<AUX>(w[2], ib, (uint32_t)(2 * yfirst) * rb, g);
 #pragma unroll
     for (int d = 0; d < D; d++) {  // trips 0 .. D-1 (clamped: rows past the segment are requested, never consumed)
         const int ya = yfirst + dir * min(d, n - 1);
-        load_row(w[3 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + dir, hi) * rb, g);
-        load_row(w[4 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + 2 * dir, hi) * rb, g);
+        load_row<AUX>(w[3 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + dir, hi) * rb, g);
+        load_row<AUX>(w[4 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + 2 * dir, hi) * rb, g);
     }
     for (int t = 0; t < n; t++) {
         const int yo = yfirst + dir * t;
         const int yn = yfirst + dir * min(t + D, n - 1);
-        load_row(w[3 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + dir, hi) * rb, g);
-        load_row(w[4 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + 2 * dir, hi) * rb, g);
+        load_row<AUX>(w[3 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + dir, hi) * rb, g);
+        load_row<AUX>(w[4 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + 2 * dir, hi) * rb, g);
         if (dir > 0) reduce_row(w[0], w[1], w[2], w[3], w[4], g, ob, (uint32_t)yo * orb);  // wave-uniform
         else reduce_row(w[4], w[3], w[2], w[1], w[0], g, ob, (uint32_t)yo * orb);
 #pragma unroll
@@ -494,50 +497,46 @@ __device__ __forceinline__ float gain_of(float s, float high, const CurveLds& t)
     return curve_eval(t, s);
 }
 
-// The streaming kernel's form of getY() for the 33-point contrast polyline (DevCurveLut):
-// j = #{x[i] < s} from one 16-byte LDS bucket read + two compares for s below 1.75 p, from ten
-// compares against wave-uniform (scalar-register) abscissae above it; x[j-1], y[j-1], m[j-1] then come
-// from LDS. Exactly curve_eval()'s result; degenerate curves take curve_eval()'s literal scan.
-constexpr int kContrastPts = 33;  // 3 x generateCurve(i <= 10), contrast_curve_generate.comp:72-86
-constexpr int kTailPts = kContrastPts - kLutTailFirst;
+// The streaming kernel's form of getY() for the 33-point contrast polyline (DevCurveLut): two 16-byte LDS reads and
+// no branch. Exactly curve_eval()'s result for every float s:
+//   * s is first clamped with sf = min(s, 2): NaN becomes 2 (v_min_f32 returns the other operand), as do +inf and every
+//     s > 2; all of them lie above x[32] = 1, where getY() matches no interval and returns 0 — and so does the table
+//     (j = 33, segment {0, 0, 0});
+//   * j = #{x[i] < sf} from the fine or the coarse bucket (musica_device.h); j in 1..32 -> the interval [x[j-1], x[j]];
+//   * j = 0 means sf <= x[0] = 0: getY() returns y[0] for sf == 0 (also -0) and 0 for negative sf.
+// Degenerate curves (lut.ok == 0) take curve_eval()'s literal scan.
 struct LutLds {
-    float4 bucket[kLutBuckets];
+    float4 bucket[kLutBuckets + kLutCoarse];
+    float4 seg[kLutPoints + 1];
     float inv_w;
     uint32_t ok;
 };
 __device__ __noinline__ float curve_eval_slow(const CurveLds* t, float s) { return curve_eval(*t, s); }
-__device__ __forceinline__ float curve_eval_lut(const float (&xt)[kTailPts], const CurveLds& t, const LutLds& lut, bool lut_ok, float s) {
+__device__ __forceinline__ float curve_eval_lut(const CurveLds& t, const LutLds& lut, bool lut_ok, float s) {
     if (!lut_ok) return curve_eval_slow(&t, s);  // wave-uniform
-    if (!(s >= 0.0f)) return 0.0f;               // negative or NaN: no interval of getY() matches
-    const float kf = s * lut.inv_w;
-    int j;
-    if (kf < (float)kLutBuckets) {
-        const float4 e = lut.bucket[(int)kf];
-        j = (int)e.x + (e.y < s ? 1 : 0) + (e.z < s ? 1 : 0);
-    } else {
-        j = kLutTailFirst;
-#pragma unroll
-        for (int i = 0; i < kTailPts; i++) j += (xt[i] < s) ? 1 : 0;
-    }
-    if (j == 0) return (t.x[0] == s) ? t.y[0] : 0.0f;
-    if (j >= kContrastPts) return 0.0f;
-    return t.m[j - 1] * (s - t.x[j - 1]) + t.y[j - 1];
+    const float sf = fminf(s, 2.0f);
+    const float kf = sf * lut.inv_w;
+    const int fine = (int)kf;                                                    // only used when kf < 256 (kf >= 0 there)
+    const int coarse = kLutBuckets + (int)fminf(sf * 256.0f, (float)(kLutCoarse - 1));
+    const float4 e = lut.bucket[kf < (float)kLutBuckets ? max(fine, 0) : max(coarse, kLutBuckets)];
+    const int j = (int)e.x + (e.y < sf ? 1 : 0) + (e.z < sf ? 1 : 0);
+    const float4 g = lut.seg[j];
+    const float r = g.z * (sf - g.x) + g.y;
+    return sf < 0.0f ? 0.0f : r;
 }
 
 template <int GAIN, bool NR, int T>
 __global__ __launch_bounds__(kBlockThreads) void k_expand_fast(ExpandArgs a) {
     __shared__ CurveLds tab;
-    __shared__ LutLds lut;
+    __shared__ __attribute__((aligned(16))) LutLds lut;
     const int img = blockIdx.z;
-    float xt[kTailPts];
     if (GAIN == GAIN_CURVE) {
         const DevCurve* cv = a.curves + (size_t)img * a.curve_stride;
         const DevCurveLut* lv = a.luts + (size_t)img * MUSICA_COARSER_LEVELS_START;
         curve_to_lds(tab, cv);
-        for (int i = threadIdx.x; i < kLutBuckets; i += blockDim.x) lut.bucket[i] = lv->bucket[i];
+        for (int i = threadIdx.x; i < kLutBuckets + kLutCoarse; i += blockDim.x) lut.bucket[i] = lv->bucket[i];
+        for (int i = threadIdx.x; i <= kLutPoints; i += blockDim.x) lut.seg[i] = lv->seg[i];
         if (threadIdx.x == 0) { lut.inv_w = lv->inv_w; lut.ok = lv->ok; }
-#pragma unroll
-        for (int i = 0; i < kTailPts; i++) xt[i] = cv->x[kLutTailFirst + i];  // uniform address -> scalar loads
         __syncthreads();
     }
     const bool lut_ok = GAIN == GAIN_CURVE && lut.ok != 0;
@@ -603,8 +602,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_expand_fast(ExpandArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     // contrast_curve_apply.comp:61
-                    float pe = be[t][j] * (GAIN == GAIN_CURVE ? curve_eval_lut(xt, tab, lut, lut_ok, se[t][j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? se[t][j] : 0.0f, a.high, tab));
-                    float po = bo[t][j] * (GAIN == GAIN_CURVE ? curve_eval_lut(xt, tab, lut, lut_ok, so[t][j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? so[t][j] : 0.0f, a.high, tab));
+                    float pe = be[t][j] * (GAIN == GAIN_CURVE ? curve_eval_lut(tab, lut, lut_ok, se[t][j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? se[t][j] : 0.0f, a.high, tab));
+                    float po = bo[t][j] * (GAIN == GAIN_CURVE ? curve_eval_lut(tab, lut, lut_ok, so[t][j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? so[t][j] : 0.0f, a.high, tab));
                     if (NR) {
                         pe = pe * fe[j];   // noise_reduction.comp:57
                         po = po * fo[j];
@@ -692,7 +691,13 @@ void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* 
                    int rows_per_wave, bool force_generic, int tag) {
     if (fast_ok(li.S) && !force_generic) {
         const dim3 grid = stream_grid(li.S, lo.S, rows_per_wave, batch);
-        auto* kern = tag == 0 ? k_reduce_fast_pf<1, 0> : tag == 1 ? k_reduce_fast_pf<1, 1> : tag == 2 ? k_reduce_fast_pf<1, 2> : k_reduce_fast_pf<1, 3>;
+        auto* kern = tag == 0 ? k_reduce_fast_pf<1, 0> : tag == 1 ? k_reduce_fast_pf<1, 1> : tag == 2 ? k_reduce_fast_pf<1, 2> : tag == 3 ? k_reduce_fast_pf<1, 3> : k_reduce_fast_pf<1, 4>;
+        if (tag == 4) {   // experiments on the stand-alone rotating launch: prefetch depth and cache policy of the streaming loads
+            static const int d = getenv("MUSICA_REDUCE_D") ? atoi(getenv("MUSICA_REDUCE_D")) : 1;
+            static const int aux = getenv("MUSICA_REDUCE_AUX") ? atoi(getenv("MUSICA_REDUCE_AUX")) : 0;
+            if (d == 2) kern = aux == 2 ? k_reduce_fast_pf<2, 4, 2> : k_reduce_fast_pf<2, 4, 0>;
+            else if (aux == 2) kern = k_reduce_fast_pf<1, 4, 2>;
+        }
         hipLaunchKernelGGL(kern, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
     } else {
         hipLaunchKernelGGL(k_reduce_generic, generic_grid(lo.S, batch), kGenericBlock, 0, st, in, out, li.S, li.pitch,

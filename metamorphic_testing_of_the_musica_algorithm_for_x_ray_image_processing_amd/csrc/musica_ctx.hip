@@ -1361,7 +1361,7 @@ int musica_k_reduce_timed_rot(musica_ctx* c, const float* d_in, uint32_t side, u
     HIP_OK(hipEventCreate(&b));
     HIP_OK(hipEventRecord(a, c->stream));
     for (uint32_t i = 0; i < iters; i++)
-        launch_reduce(c->stream, d_in + (size_t)(i % nbuf) * li.plane, li, d_out + (size_t)(i % nbuf) * lo.plane, lo, 1, rpw, c->generic, 2);
+        launch_reduce(c->stream, d_in + (size_t)(i % nbuf) * li.plane, li, d_out + (size_t)(i % nbuf) * lo.plane, lo, 1, rpw, c->generic, 4);
     HIP_OK(hipEventRecord(b, c->stream));
     HIP_OK(hipEventSynchronize(b));
     float ms = 0.f;

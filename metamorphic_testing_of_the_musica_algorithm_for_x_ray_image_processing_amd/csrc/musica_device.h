@@ -48,21 +48,29 @@ struct DevCurve {
     uint32_t pad;
 };
 
-// Exact accelerator for getY() on a 33-point contrast curve (levels 0..2). Texels with
-// s * inv_w < kLutBuckets fall into a uniform bucket that stores how many curve abscissae lie in
-// lower buckets (jlo) and the at most two abscissae inside it (xa <= xb, +inf when absent):
+// Exact accelerator for getY() on a 33-point contrast curve (levels 0..2): j = #{x[i] < s} from ONE 16-byte table read
+// and two compares, then the segment (x[j-1], y[j-1], slope[j-1]) from a second 16-byte read — no branches.
+//   fine table   : s * inv_w < kLutBuckets (s below 1.75 p): uniform buckets over [0, 1.75 p); a bucket stores how many
+//                  abscissae lie in lower buckets (jlo) and the at most two inside it (xa <= xb, +inf when absent);
+//   coarse table : every other s: buckets of width 1 / 256 over [0, 1] (index min(int(s * 256), kLutCoarse - 1)); only the
+//                  10 abscissae of the last Bezier span (x[23..32], spaced >= 0.01 apart) can lie at or above 1.75 p, so
+//                  jlo = 23 + (tail abscissae in lower coarse buckets) and the bucket holds at most two of them;
 //   #{x[i] < s} = jlo + (xa < s) + (xb < s).
-// Bucket membership is decided by the same float expression (int)(x * inv_w) when the table is built
-// and when it is read, and that expression is monotone in x, so the count is exact whatever the
-// rounding. Larger s only has the 10 abscissae of the last Bezier span left to compare with.
-// ok == 0 (degenerate curve, e.g. maxBin == 0) sends the level down the literal scan instead.
-constexpr int kLutBuckets = 256;
-constexpr int kLutTailFirst = 23;   // abscissae 0..22 are <= 1.4 p and always inside the table's range
+// Bucket membership is decided by the same float expressions when the table is built and when it is read, and both are
+// monotone in x, so the count is exact whatever the rounding: an abscissa in a lower bucket is < s, one in a higher bucket
+// is > s (proof in DESIGN.md, "Exactness notes"). The builder verifies that exactly abscissae 0..22 fall inside the fine
+// table, that no bucket holds three and that x[0] == 0; otherwise (e.g. maxBin == 0) ok = 0 and the level takes the
+// literal scan.
+constexpr int kLutBuckets = 256;    // fine buckets
+constexpr int kLutCoarse = 258;     // coarse buckets: int(s * 256) = 0 .. 256, and one for everything above
+constexpr int kLutTailFirst = 23;   // abscissae 0..22 are <= 1.4 p and always inside the fine table's range
+constexpr int kLutPoints = 33;      // 3 x generateCurve(i <= 10), contrast_curve_generate.comp:72-86
 struct DevCurveLut {
     float inv_w;
     uint32_t ok;
     uint32_t pad0, pad1;
-    float4 bucket[kLutBuckets];     // {jlo (as float), xa, xb, unused}
+    float4 bucket[kLutBuckets + kLutCoarse];   // {jlo (as float), xa, xb, unused}
+    float4 seg[kLutPoints + 1];                 // seg[j] = {x[j-1], y[j-1], slope[j-1], 0}; seg[0] = {x[0], y[0], 0, 0}; seg[33] = 0
 };
 
 struct LevelDesc {

