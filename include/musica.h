@@ -162,6 +162,9 @@ uint32_t musica_get_image_size(const musica_ctx* ctx);
 uint32_t musica_get_levels(const musica_ctx* ctx);
 uint32_t musica_get_batch(const musica_ctx* ctx);
 /* Side of pyramid level `level` (S_0 = N, S_{i+1} = ceil(S_i / 2); level may be L for the residual). */
+/* 1 when the level-0 expand launch of this context also accumulates the gradation histogram (no separate pass over the
+ * reconstructed image; bench.py prices the launch accordingly), else 0. */
+int musica_fuses_gradation_histogram(const musica_ctx* ctx);
 uint32_t musica_get_level_size(const musica_ctx* ctx, uint32_t level);
 
 /* ---- the hot path ---------------------------------------------------- */

@@ -20,13 +20,15 @@ namespace musica {
 // minmax[b] = {min = 0xFFFFFFFF at word 0, max = 0 at word kMaxWord} (one 64-byte line each: the atomics of different
 // images and of min / max then go to different L2 channels); noise_hist[b][4][2048] = 0; grad_hist[b][1024] = 0; clahe hist = 0.
 __global__ void k_clear(uint32_t* __restrict__ minmax, uint32_t* __restrict__ noise_hist, uint32_t* __restrict__ grad_hist,
-                        uint32_t* __restrict__ clahe_hist, int batch) {
+                        uint32_t* __restrict__ clahe_hist, int batch, uint32_t* __restrict__ grad_hist_b, uint32_t* __restrict__ gzero) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int nh = batch * 4 * MUSICA_NOISE_BINS, gh = batch * MUSICA_GRAD_BINS;
     const int ch = clahe_hist ? batch * MUSICA_CLAHE_TILES * MUSICA_CLAHE_TILES * MUSICA_CLAHE_BINS : 0;
     if (minmax && i < batch) { minmax[kMinMaxStride * i] = 0xFFFFFFFFu; minmax[kMinMaxStride * i + kMaxWord] = 0u; }
     if (noise_hist && i < nh) noise_hist[i] = 0u;
     if (grad_hist && i < gh) grad_hist[i] = 0u;
+    if (grad_hist_b && i < gh) grad_hist_b[i] = 0u;
+    if (gzero && i < batch) gzero[i] = 0u;
     if (i < ch) clahe_hist[i] = 0u;
 }
 
@@ -326,8 +328,17 @@ __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long k
 __device__ __forceinline__ void noise_curves_block(int level, int img, const uint32_t* __restrict__ hist, size_t hist_stride,
                                                    musica_hist_max_point* __restrict__ maxpts, DevCurve* __restrict__ curves,
                                                    const musica_contrast_params* __restrict__ cparams, int levels,
-                                                   DevCurveLut* __restrict__ luts) {
+                                                   DevCurveLut* __restrict__ luts, const uint32_t* __restrict__ minmax, int min_chain_exact,
+                                                   int* __restrict__ thr090) {
     __shared__ unsigned long long scratch[16];
+    // the `normalized <= 0.9` test of img_relevant.comp:56 as a threshold on the raw pixel (norm_threshold_090), once per image:
+    // the level-0 expand kernel reads it when it accumulates the gradation histogram. The block of the coarsest level has the
+    // least work of its own (two-point curve, no table).
+    if (thr090 && level == levels - 1 && threadIdx.x == 255) {
+        float minv, maxv;
+        chain_scalars(minmax, img, min_chain_exact, minv, maxv);
+        thr090[img] = norm_threshold_090(minv, maxv - minv);
+    }
     __shared__ float sx[kCurveCap];
     __shared__ int sbucket[kCurveCap];
     __shared__ int sok;
@@ -428,8 +439,9 @@ __device__ __forceinline__ void noise_curves_block(int level, int img, const uin
 __global__ __launch_bounds__(256) void k_noise_curves(const uint32_t* __restrict__ hist, size_t hist_stride,
                                                       musica_hist_max_point* __restrict__ maxpts, DevCurve* __restrict__ curves,
                                                       const musica_contrast_params* __restrict__ cparams, int levels,
-                                                      DevCurveLut* __restrict__ luts) {
-    noise_curves_block(blockIdx.x, blockIdx.y, hist, hist_stride, maxpts, curves, cparams, levels, luts);
+                                                      DevCurveLut* __restrict__ luts, const uint32_t* __restrict__ minmax, int min_chain_exact,
+                                                      int* __restrict__ thr090) {
+    noise_curves_block(blockIdx.x, blockIdx.y, hist, hist_stride, maxpts, curves, cparams, levels, luts, minmax, min_chain_exact, thr090);
 }
 
 // K12 + K13 and K15 in one launch: workgroups 0 .. levels-1 of an image build that level's curve, the others each
@@ -440,10 +452,11 @@ __global__ __launch_bounds__(256) void k_curves_cnr(const uint32_t* __restrict__
                                                     musica_hist_max_point* __restrict__ maxpts, DevCurve* __restrict__ curves,
                                                     const musica_contrast_params* __restrict__ cparams, int levels,
                                                     DevCurveLut* __restrict__ luts, const float* __restrict__ sdev, float* __restrict__ cnr,
-                                                    int S, int pitch, size_t plane, int tiles_x) {
+                                                    int S, int pitch, size_t plane, int tiles_x, const uint32_t* __restrict__ minmax,
+                                                    int min_chain_exact, int* __restrict__ thr090) {
     const int img = blockIdx.y;
     if ((int)blockIdx.x < levels) {   // block-uniform
-        noise_curves_block(blockIdx.x, img, hist, hist_stride, maxpts, curves, cparams, levels, luts);
+        noise_curves_block(blockIdx.x, img, hist, hist_stride, maxpts, curves, cparams, levels, luts, minmax, min_chain_exact, thr090);
         return;
     }
     __shared__ unsigned long long scratch2[16];
@@ -532,10 +545,11 @@ __global__ __launch_bounds__(256) void k_stats(const float* __restrict__ cnr, in
 // host-side launchers
 // ======================================================================================
 
-void launch_clear(hipStream_t st, uint32_t* minmax, uint32_t* noise_hist, uint32_t* grad_hist, uint32_t* clahe_hist, int batch) {
+void launch_clear(hipStream_t st, uint32_t* minmax, uint32_t* noise_hist, uint32_t* grad_hist, uint32_t* clahe_hist, int batch, uint32_t* grad_hist_b,
+                  uint32_t* gzero) {
     int n = batch * 4 * MUSICA_NOISE_BINS;
     if (clahe_hist) n = max(n, batch * MUSICA_CLAHE_TILES * MUSICA_CLAHE_TILES * MUSICA_CLAHE_BINS);
-    hipLaunchKernelGGL(k_clear, dim3((n + 255) / 256), dim3(256), 0, st, minmax, noise_hist, grad_hist, clahe_hist, batch);
+    hipLaunchKernelGGL(k_clear, dim3((n + 255) / 256), dim3(256), 0, st, minmax, noise_hist, grad_hist, clahe_hist, batch, grad_hist_b, gzero);
 }
 
 void launch_minmax(hipStream_t st, const uint16_t* px, int N, uint32_t* minmax, int batch) {
@@ -581,16 +595,18 @@ void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& 
 }
 
 void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves,
-                         const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts) {
-    hipLaunchKernelGGL(k_noise_curves, dim3(levels, batch), dim3(256), 0, st, hist, hist_stride, maxpts, curves, cparams, levels, luts);
+                         const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const uint32_t* minmax, int min_chain_exact,
+                         int* thr090) {
+    hipLaunchKernelGGL(k_noise_curves, dim3(levels, batch), dim3(256), 0, st, hist, hist_stride, maxpts, curves, cparams, levels, luts, minmax,
+                       min_chain_exact, thr090);
 }
 
 void launch_curves_cnr(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves,
                        const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const float* sdev, float* cnr,
-                       const LevelDesc& l3) {
+                       const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact, int* thr090) {
     const int tiles_x = (l3.S + 31) / 32, tiles_y = (l3.S + 7) / 8;
     hipLaunchKernelGGL(k_curves_cnr, dim3(levels + tiles_x * tiles_y, batch), dim3(256), 0, st, hist, hist_stride, maxpts, curves, cparams, levels,
-                       luts, sdev, cnr, l3.S, l3.pitch, l3.plane, tiles_x);
+                       luts, sdev, cnr, l3.S, l3.pitch, l3.plane, tiles_x, minmax, min_chain_exact, thr090);
 }
 
 void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& l3, const musica_hist_max_point* maxpts, int levels,

@@ -155,6 +155,23 @@ __device__ __forceinline__ int norm_threshold_090(float minv, float den) {
     return lo;
 }
 
+// Relevance weight uint(relevant * 100) (img_relevant.comp:44-63, gradation_histogram.comp:30) of one cnr texel, split
+// into the part that depends only on cnr (shared by all the pixels under that texel) and the per-pixel tests:
+//   w = inside ? (ramp ? w_ramp : (high && pixel <= 0.9 ? 100 : 0)) : 0.     `c` is cnr * 256 already;
+// pow(r, 5.0) is restated as ((r*r)*(r*r))*r (oracle Q5).
+struct CnrClass {
+    uint32_t w_ramp;  // uint(((r*r)*(r*r))*r * 100) for 1 <= cnr <= 6, r = cnr / 6
+    bool ramp, high;  // 1 <= cnr <= 6 (first branch wins at cnr == 6) ; 6 <= cnr <= 256
+};
+__device__ __forceinline__ CnrClass classify_cnr(float c) {
+    CnrClass k;
+    k.ramp = c >= 1.0f && c <= 6.0f;
+    k.high = c >= 6.0f && c <= kMaxCnrValue;
+    const float r = c / 6.0f;
+    k.w_ramp = f2u((((r * r) * (r * r)) * r) * 100.0f);
+    return k;
+}
+
 // 16-byte load of 4 consecutive floats of a row; columns >= valid_cols come back as 0.
 // `row` must be 16-byte aligned at column x (x % 4 == 0) and x < pitch.
 __device__ __forceinline__ float4 load4_guard(const float* __restrict__ row, int x, int valid_cols) {

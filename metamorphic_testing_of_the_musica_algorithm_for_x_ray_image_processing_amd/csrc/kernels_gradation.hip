@@ -34,22 +34,6 @@ __device__ __forceinline__ float cnr_at(const float* __restrict__ cnr, int cnrS,
 // columns of a 16-row group (one 16-byte load per row), finds its columns' first zeros, the 4 lanes
 // of an area combine them with two DPP/shuffle steps, and every pixel before that position is
 // binned with weight uint(relevant * 100) into an LDS-private histogram.
-// Relevance weight uint(relevant * 100) (img_relevant.comp:44-63, gradation_histogram.comp:30) of one cnr
-// texel, split into the part that depends only on cnr (shared by all the pixels under that texel) and the
-// per-pixel tests: w = inside ? (ramp ? w_ramp : (high && pixel <= 0.9 ? 100 : 0)) : 0.
-struct CnrClass {
-    uint32_t w_ramp;  // uint(((r*r)*(r*r))*r * 100) for 1 <= cnr <= 6, r = cnr / 6
-    bool ramp, high;  // 1 <= cnr <= 6 (first branch wins at cnr == 6) ; 6 <= cnr <= 256
-};
-__device__ __forceinline__ CnrClass classify_cnr(float c) {
-    CnrClass k;
-    k.ramp = c >= 1.0f && c <= 6.0f;
-    k.high = c >= 6.0f && c <= kMaxCnrValue;
-    const float r = c / 6.0f;
-    k.w_ramp = f2u((((r * r) * (r * r)) * r) * 100.0f);
-    return k;
-}
-
 // SHARED8: the cnr scale is a multiple of 8 (always the case for N >= 57: scale = ceil(N / ceil(N/8)) = 8), so
 // the 4 columns of a lane and each half (8 rows) of a 16-row group sit under ONE cnr texel: two cnr loads
 // and two classifications per lane and group instead of 64.
@@ -60,8 +44,9 @@ template <bool SHARED8, bool RAW>
 __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
     __shared__ uint32_t lh[MUSICA_GRAD_BINS + 64];  // + one scratch word per lane for the branch-free adds
     __shared__ int s_thr;
-    for (int i = threadIdx.x; i < MUSICA_GRAD_BINS + 64; i += blockDim.x) lh[i] = 0u;
     const int img = blockIdx.z;
+    if (a.only_if && a.only_if[img] == 0u) return;   // block-uniform: nothing to redo for this image
+    for (int i = threadIdx.x; i < MUSICA_GRAD_BINS + 64; i += blockDim.x) lh[i] = 0u;
     if (RAW && threadIdx.x == 0) {
         float minv, maxv;
         chain_scalars(a.minmax, img, a.min_chain_exact, minv, maxv);
@@ -268,14 +253,21 @@ __device__ __forceinline__ void block_max_max(uint32_t& a, uint32_t& b, uint32_t
 
 // One block of 1024 threads per image: thread i owns bin i.
 // gradation_curve_generate.comp:50-193. All integer arithmetic is uint32 and wraps, like GLSL's uint.
-__global__ __launch_bounds__(1024) void k_grad_curve(const uint32_t* __restrict__ hist, musica_hist_max_point* __restrict__ gmax,
-                                                     DevCurve* __restrict__ curves) {
+// hist_b / gzero (may be NULL): images whose gzero word is set take their histogram from hist_b — the literal
+// k_grad_hist pass that ran behind the fused expand kernel — and copy it into hist so that every getter sees it.
+__global__ __launch_bounds__(1024) void k_grad_curve(uint32_t* __restrict__ hist, musica_hist_max_point* __restrict__ gmax,
+                                                     DevCurve* __restrict__ curves, const uint32_t* __restrict__ hist_b,
+                                                     const uint32_t* __restrict__ gzero) {
     __shared__ uint32_t cnt[MUSICA_GRAD_BINS];
     __shared__ uint32_t s32[16], s32b[16];
     __shared__ unsigned long long s64[16];
     const int img = blockIdx.x;
     const uint32_t i = threadIdx.x;
-    const uint32_t raw = hist[(size_t)img * MUSICA_GRAD_BINS + i];
+    uint32_t raw = hist[(size_t)img * MUSICA_GRAD_BINS + i];
+    if (gzero && gzero[img] != 0u) {
+        raw = hist_b[(size_t)img * MUSICA_GRAD_BINS + i];
+        hist[(size_t)img * MUSICA_GRAD_BINS + i] = raw;
+    }
     const uint32_t count = raw / 100u;                                           // :68
     cnt[i] = count;
     // K12 on the raw histogram (src/vk_processing.cpp:2499, first maximum wins) and the two window sums, one pass
@@ -348,17 +340,37 @@ __global__ __launch_bounds__(256) void k_grad_apply(const float* __restrict__ in
     __syncthreads();
     in += (size_t)img * plane;
     out += (size_t)img * plane;
-    const int vec_per_row = pitch >> 2;
-    const size_t total = (size_t)vec_per_row * N;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int y = (int)(i / vec_per_row), x = (int)(i % vec_per_row) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(in + (size_t)y * pitch + x);
+    // rows are pitched to a multiple of 4 floats, so a plane is a dense run of 16-byte groups (pad columns are processed too:
+    // they hold zeros and nobody reads them). U groups per thread and trip, all loads issued before the first lookup: with one
+    // load in flight per lane the kernel is bound by latency, not bandwidth (4.7 TB/s; 8192 wavefronts x 1 KiB = 8 MB in flight).
+    constexpr int U = 4;
+    const size_t total = (size_t)(pitch >> 2) * N;
+    const float4* src = reinterpret_cast<const float4*>(in);
+    float4* dst = reinterpret_cast<float4*>(out);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < total; i += U * stride) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float4 o;
+            o.x = curve_eval(tab, v[u].x);                                      // img_apply_gradation_curve.comp:44
+            o.y = curve_eval(tab, v[u].y);
+            o.z = curve_eval(tab, v[u].z);
+            o.w = curve_eval(tab, v[u].w);
+            dst[i + u * stride] = o;
+        }
+    }
+    for (; i < total; i += stride) {
+        const float4 v = src[i];
         float4 o;
-        o.x = curve_eval(tab, v.x);                                             // img_apply_gradation_curve.comp:44
+        o.x = curve_eval(tab, v.x);
         o.y = curve_eval(tab, v.y);
         o.z = curve_eval(tab, v.z);
         o.w = curve_eval(tab, v.w);
-        *reinterpret_cast<float4*>(out + (size_t)y * pitch + x) = o;
+        dst[i] = o;
     }
 }
 
@@ -393,8 +405,8 @@ void launch_relevant(hipStream_t st, const float* normalized, const float* cnr, 
                        l0.plane, l3.S, l3.pitch, l3.plane, cnrScale);
 }
 
-void launch_grad_curve(hipStream_t st, const uint32_t* hist, musica_hist_max_point* gmax, DevCurve* curves, int batch) {
-    hipLaunchKernelGGL(k_grad_curve, dim3(batch), dim3(1024), 0, st, hist, gmax, curves);
+void launch_grad_curve(hipStream_t st, uint32_t* hist, musica_hist_max_point* gmax, DevCurve* curves, int batch, const uint32_t* hist_b, const uint32_t* gzero) {
+    hipLaunchKernelGGL(k_grad_curve, dim3(batch), dim3(1024), 0, st, hist, gmax, curves, hist_b, gzero);
 }
 
 void launch_grad_apply(hipStream_t st, const float* in, float* out, const LevelDesc& l0, const DevCurve* curves, int batch) {

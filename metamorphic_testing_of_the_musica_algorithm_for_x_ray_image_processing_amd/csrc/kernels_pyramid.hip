@@ -525,11 +525,21 @@ __device__ __forceinline__ float curve_eval_lut(const CurveLds& t, const LutLds&
     return sf < 0.0f ? 0.0f : r;
 }
 
-template <int GAIN, bool NR, int T>
-__global__ __launch_bounds__(kBlockThreads) void k_expand_fast(ExpandArgs a) {
+// GH (level 0 only): the launch also accumulates the gradation histogram — img_relevant.comp + gradation_histogram.comp —
+// of the texels it reconstructs, while they are still in registers (the reference re-reads the whole image for it).
+// The reference's thread walks a 16 x 16 area and `return`s at the first texel that is exactly 0
+// (gradation_histogram.comp:24); here every texel is binned and a zero only raises the image's gzero word: the literal
+// kernel (k_grad_hist) then recounts that image into a second histogram and k_grad_curve takes that one. The relevance
+// weight uint(relevant * 100) is the one k_grad_hist computes: one cnr classification per lane and row pair (the cnr scale
+// is 8 here, so a lane's 8 columns and both rows of a pair sit under one cnr texel), `normalized <= 0.9` on the raw pixel.
+template <int GAIN, bool NR, int T, bool GH, int W = 1>
+__global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) {
     __shared__ CurveLds tab;
     __shared__ __attribute__((aligned(16))) LutLds lut;
+    __shared__ uint32_t lh[GH ? MUSICA_GRAD_BINS + 64 : 1];  // + one scratch word per lane for the branch-free adds
     const int img = blockIdx.z;
+    if (GH)
+        for (int i = threadIdx.x; i < MUSICA_GRAD_BINS + 64; i += blockDim.x) lh[i] = 0u;
     if (GAIN == GAIN_CURVE) {
         const DevCurve* cv = a.curves + (size_t)img * a.curve_stride;
         const DevCurveLut* lv = a.luts + (size_t)img * MUSICA_COARSER_LEVELS_START;
@@ -545,24 +555,37 @@ __global__ __launch_bounds__(kBlockThreads) void k_expand_fast(ExpandArgs a) {
     const int lane = threadIdx.x & 63;
     const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
     const int k0 = seg * a.rows_per_wave;
-    if (k0 >= a.Sc) return;
+    bool saw_zero = false;
+    if (k0 < a.Sc) {   // wave-uniform
     const int k1 = min(k0 + a.rows_per_wave, a.Sc);
     const int S = a.S;
     const Buf bb = make_buf(a.band + (size_t)img * a.plane, a.plane * 4);
     const Buf sb = make_buf((GAIN != GAIN_CONST ? a.sdev : a.band) + (size_t)img * a.plane, a.plane * 4);
     const Buf ob = make_buf(a.recon + (size_t)img * a.plane, a.plane * 4);
     const Buf pb = make_buf(a.prev + (size_t)img * a.cplane, a.cplane * 4);
+    const Buf wb = GH ? make_buf(a.raw + (size_t)img * S * S, (size_t)S * S * 2) : bb;
     const float* cnr = NR ? a.cnr + (size_t)img * a.cnrPlane : nullptr;
     const LaneCfg g = make_cfg(blockIdx.x, lane, S);
     const uint32_t rb = (uint32_t)a.pitch * 4u, crb = (uint32_t)a.cpitch * 4u;
+    const uint32_t urb = (uint32_t)S * 2u, uoff = g.off == kOob ? kOob : g.off >> 1;
     // noise reduction: the 8 columns of a lane share ceil(8 / scale) cnr texels per row
     const int cxs[2] = {g.active ? g.c / a.cnrScale : 0, g.active ? (g.c + 4) / a.cnrScale : 0};
+    // gradation histogram: img_relevant.comp:46-49 in uint arithmetic (wraps for N < 100 like the shader)
+    const uint32_t border = 100u, lim = (uint32_t)S - border;
+    uint32_t colin = 0u;
+    if (GH) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (g.active && (uint32_t)(g.c + j) > border && (uint32_t)(g.c + j) < lim) colin |= 1u << j;
+    }
+    const int thr = GH ? a.thr090[img] : 0;
 
     CRow cw[T + 2];
     load_crow(cw[0], pb, (uint32_t)coarse_of_fine(2 * k0 - 2, S) * crb, g);
     load_crow(cw[1], pb, (uint32_t)k0 * crb, g);
     for (int k = k0; k < k1; k += T) {
         float be[T][8], bo[T][8], se[T][8], so[T][8];
+        float4 we[T], wo[T];   // raw uint16 rows (GH)
 #pragma unroll
         for (int t = 0; t < T; t++) {
             const int ka = min(k + t, k1 - 1);
@@ -573,6 +596,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_expand_fast(ExpandArgs a) {
                 load8(se[t], sb, g.off + (uint32_t)(2 * ka) * rb);
                 load8(so[t], sb, g.off + (uint32_t)(2 * ka + 1) * rb);
             }
+            if (GH) {
+                we[t] = bload4(wb, uoff + (uint32_t)(2 * ka) * urb);
+                wo[t] = bload4(wb, uoff + (uint32_t)(2 * ka + 1) * urb);
+            }
         }
 #pragma unroll
         for (int t = 0; t < T; t++) {
@@ -581,10 +608,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_expand_fast(ExpandArgs a) {
                 float lowE[8], lowO[8];
                 lowpass_pair(cw[t], cw[t + 1], cw[t + 2], g, lowE, lowO);
                 float fe[8], fo[8];  // noise-reduction factors of the two rows
+                float cnr_pair = 0.0f;   // cnr * 256 of the texel above this lane's row pair (GH: scale 8)
                 if (NR) {
                     const size_t re = (size_t)((2 * kk) / a.cnrScale) * a.cnrPitch, ro = (size_t)((2 * kk + 1) / a.cnrScale) * a.cnrPitch;
                     if (a.cnrScale == 4 || a.cnrScale == 8) {  // columns c..c+3 and c+4..c+7 each sit inside one cnr texel (c % 8 == 0)
-                        const float e0 = nr_factor_m(cnr[re + cxs[0]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
+                        cnr_pair = cnr[re + cxs[0]] * kMaxCnrValue;
+                        const float e0 = nr_factor_m(cnr_pair, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
                         const float e1 = nr_factor_m(cnr[re + cxs[1]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
                         const float o0 = nr_factor_m(cnr[ro + cxs[0]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
                         const float o1 = nr_factor_m(cnr[ro + cxs[1]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
@@ -599,23 +628,56 @@ __global__ __launch_bounds__(kBlockThreads) void k_expand_fast(ExpandArgs a) {
                         }
                     }
                 }
+                // img_relevant.comp:44-63 for the cnr texel above the row pair (rows 2kk, 2kk+1 and columns c..c+7 share it)
+                const CnrClass kc = classify_cnr(cnr_pair);
+                const uint32_t w_cnr = kc.ramp ? kc.w_ramp : 0u, w_dark_or_ramp = kc.ramp ? kc.w_ramp : (kc.high ? 100u : 0u);   // bright / dark pixel under this texel
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    // contrast_curve_apply.comp:61
-                    float pe = be[t][j] * (GAIN == GAIN_CURVE ? curve_eval_lut(tab, lut, lut_ok, se[t][j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? se[t][j] : 0.0f, a.high, tab));
-                    float po = bo[t][j] * (GAIN == GAIN_CURVE ? curve_eval_lut(tab, lut, lut_ok, so[t][j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? so[t][j] : 0.0f, a.high, tab));
-                    if (NR) {
-                        pe = pe * fe[j];   // noise_reduction.comp:57
-                        po = po * fo[j];
+                for (int ph = 0; ph < 2; ph++) {   // even row, then odd row: each is stored (and binned) before the next is touched
+                    float* b = ph ? bo[t] : be[t];
+                    const float* sd = ph ? so[t] : se[t];
+                    const float* low = ph ? lowO : lowE;
+                    const float* f = ph ? fo : fe;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        // contrast_curve_apply.comp:61
+                        float p = b[j] * (GAIN == GAIN_CURVE ? curve_eval_lut(tab, lut, lut_ok, sd[j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? sd[j] : 0.0f, a.high, tab));
+                        if (NR) p = p * f[j];   // noise_reduction.comp:57
+                        b[j] = low[j] + p;      // img_addition.comp:15
                     }
-                    be[t][j] = lowE[j] + pe;   // img_addition.comp:15
-                    bo[t][j] = lowO[j] + po;
+                    store8(ob, g.off + (uint32_t)(2 * kk + ph) * rb, b);
+                    if (GH) {
+                        const float4 wr = ph ? wo[t] : we[t];
+                        const uint32_t raw[4] = {__float_as_uint(wr.x), __float_as_uint(wr.y), __float_as_uint(wr.z), __float_as_uint(wr.w)};
+                        const uint32_t y = (uint32_t)(2 * kk + ph);
+                        const uint32_t m = (y > border && y < lim) ? colin : 0u;   // inside-the-border bits of the lane's 8 columns in this row
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const float cur = b[j];
+                            const int px = (int)((j & 1) ? (raw[j >> 1] >> 16) : (raw[j >> 1] & 0xFFFFu));
+                            saw_zero = saw_zero || (cur == 0.0f);                        // gradation_histogram.comp:24
+                            // :26 int(cur * 1024) with "NaN never indexes" (oracle Q6) and "bins outside [0, 1024) are dropped" (Q1) folded into
+                            // one unsigned compare: max(NaN, -1) = -1 and every scaled <= -1 convert to a negative int, i.e. a huge unsigned;
+                            // (-1, 0) truncates to bin 0 like the shader's int(); everything out of range lands on the spare word 1024
+                            const uint32_t bin = min((uint32_t)(int)fminf(fmaxf(cur * (float)MUSICA_GRAD_BINS, -1.0f), 2048.0f), (uint32_t)MUSICA_GRAD_BINS);
+                            // :28-30 uint(relevant * 100): 0 outside the border; adding 0 leaves the histogram as it is
+                            const uint32_t w = ((m >> j) & 1u) * (px <= thr ? w_dark_or_ramp : w_cnr);
+                            atomicAdd(&lh[bin], w);
+                        }
+                    }
                 }
-                store8(ob, g.off + (uint32_t)(2 * kk) * rb, be[t]);
-                store8(ob, g.off + (uint32_t)(2 * kk + 1) * rb, bo[t]);
             }
         }
         cw[0] = cw[T]; cw[1] = cw[T + 1];
+    }
+    }
+    if (GH) {
+        if (saw_zero) atomicOr(&a.gzero[img], 1u);
+        __syncthreads();
+        uint32_t* gh = a.ghist + (size_t)img * MUSICA_GRAD_BINS;
+        for (int i = threadIdx.x; i < MUSICA_GRAD_BINS; i += blockDim.x) {
+            const uint32_t v = lh[i];
+            if (v) atomicAdd(&gh[i], v);
+        }
     }
 }
 
@@ -744,8 +806,15 @@ template <int GAIN, bool NR>
 static void launch_expand_t(hipStream_t st, const ExpandArgs& a, int batch, bool force_generic, int rows_per_trip) {
     if (fast_ok(a.S) && !force_generic) {
         const dim3 grid = stream_grid(a.S, a.Sc, a.rows_per_wave, batch);
-        if (rows_per_trip >= 2) hipLaunchKernelGGL((k_expand_fast<GAIN, NR, 2>), grid, dim3(kBlockThreads), 0, st, a);
-        else hipLaunchKernelGGL((k_expand_fast<GAIN, NR, 1>), grid, dim3(kBlockThreads), 0, st, a);
+        if (GAIN == GAIN_CURVE && NR && a.ghist) {   // level 0 with the gradation histogram on board (the caller checked cnrScale == 8)
+            // W = 4: register allocation capped at 128 (4 wavefronts per SIMD, 16 dwords of scratch) against 143 registers and 3 wavefronts
+            static const int occ = getenv("MUSICA_GH_OCC") ? atoi(getenv("MUSICA_GH_OCC")) : 4;
+            if (rows_per_trip >= 2) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 2, true>), grid, dim3(kBlockThreads), 0, st, a);
+            else if (occ >= 4) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 4>), grid, dim3(kBlockThreads), 0, st, a);
+            else hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 1>), grid, dim3(kBlockThreads), 0, st, a);
+        }
+        else if (rows_per_trip >= 2) hipLaunchKernelGGL((k_expand_fast<GAIN, NR, 2, false>), grid, dim3(kBlockThreads), 0, st, a);
+        else hipLaunchKernelGGL((k_expand_fast<GAIN, NR, 1, false>), grid, dim3(kBlockThreads), 0, st, a);
     } else {
         hipLaunchKernelGGL((k_expand_generic<GAIN, NR>), generic_grid(a.S, batch), kGenericBlock, 0, st, a);
     }

@@ -31,6 +31,13 @@ struct ExpandArgs {
     float lowCnr, lowFactor, highCnr, highFactor;  // NoiseReductionParams of the level
     int rows_per_wave;
     size_t curve_stride; // DevCurve elements between consecutive images
+    // Level 0 only, NULL otherwise: the launch also accumulates the gradation histogram (img_relevant.comp +
+    // gradation_histogram.comp) of the texels it has just reconstructed, see k_expand_fast<.., GH = true>.
+    const uint16_t* raw;     // raw pixels (dense rows of S): `normalized <= 0.9` is tested as raw <= thr090[image]
+    uint32_t* ghist;         // [batch][1024]
+    uint32_t* gzero;         // [batch]: set when a reconstructed texel is exactly 0 (the `return` of gradation_histogram.comp:24
+                             // then cuts the scan of its 16 x 16 area short: k_grad_hist redoes that image literally)
+    const int* thr090;       // [batch]: largest raw value whose normalized value is <= 0.9 (k_curves_cnr)
 };
 
 struct GradArgs {
@@ -45,6 +52,7 @@ struct GradArgs {
     const uint16_t* raw;     // non-NULL: test `normalized <= 0.9` on the raw pixels (dense rows of N) instead of reading `normalized`
     const uint32_t* minmax;
     int min_chain_exact;
+    const uint32_t* only_if; // non-NULL: images whose word is 0 are skipped (fix-up launch behind the fused expand kernel)
 };
 
 // kernels_pyramid.hip
@@ -58,16 +66,16 @@ void launch_lowpass(hipStream_t st, const float* coarse, float* low, const Level
 void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic, int rows_per_trip);
 void launch_exp_band(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch);
 // kernels_analysis.hip
-void launch_clear(hipStream_t st, uint32_t* minmax, uint32_t* noise_hist, uint32_t* grad_hist, uint32_t* clahe_hist, int batch);
+void launch_clear(hipStream_t st, uint32_t* minmax, uint32_t* noise_hist, uint32_t* grad_hist, uint32_t* clahe_hist, int batch, uint32_t* grad_hist_b = nullptr, uint32_t* gzero = nullptr);
 void launch_minmax(hipStream_t st, const uint16_t* px, int N, uint32_t* minmax, int batch);
 void launch_normalize(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, const uint32_t* minmax, int min_chain_exact, int batch);
 void launch_sqrt(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, int batch);
 void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch, int rows_per_wave);
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch);
-void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves, const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts);
+void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves, const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const uint32_t* minmax, int min_chain_exact, int* thr090);
 void launch_curves_cnr(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves,
                        const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const float* sdev, float* cnr,
-                       const LevelDesc& l3);
+                       const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact, int* thr090);
 void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& l3, const musica_hist_max_point* maxpts, int levels, int batch);
 void launch_selftest_exact_math(hipStream_t st, unsigned long long* d_bad4);
 void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact,
@@ -77,7 +85,7 @@ void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const u
 void launch_grad_hist(hipStream_t st, const GradArgs& a, int batch);
 void launch_grad_hist_ref(hipStream_t st, const float* img, const float* relevant, const LevelDesc& l0, uint32_t* hist, int batch);
 void launch_relevant(hipStream_t st, const float* normalized, const float* cnr, float* out, const LevelDesc& l0, const LevelDesc& l3, int cnrScale, int batch);
-void launch_grad_curve(hipStream_t st, const uint32_t* hist, musica_hist_max_point* gmax, DevCurve* curves, int batch);
+void launch_grad_curve(hipStream_t st, uint32_t* hist, musica_hist_max_point* gmax, DevCurve* curves, int batch, const uint32_t* hist_b = nullptr, const uint32_t* gzero = nullptr);
 void launch_grad_apply(hipStream_t st, const float* in, float* out, const LevelDesc& l0, const DevCurve* curves, int batch);
 // kernels_bench.hip (measurement aid)
 void launch_copy41(hipStream_t st, const float* in, float* out, int side);

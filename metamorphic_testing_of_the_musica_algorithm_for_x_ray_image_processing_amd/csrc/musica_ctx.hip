@@ -92,6 +92,10 @@ struct musica_ctx {
     musica_contrast_params* d_cparams;
     float* d_cnr;
     uint32_t* d_grad_hist;
+    uint32_t* d_grad_hist_b;   // the literal recount of images whose reconstruction holds an exact zero (fused gradation histogram)
+    uint32_t* d_gzero;         // [B]: that condition
+    int* d_thr090;             // [B]: raw-pixel form of `normalized <= 0.9`
+    bool fuse_gh;              // the level-0 expand launch accumulates the gradation histogram
     musica_hist_max_point* d_grad_max;
     DevCurve* d_gcurve;
     float* d_graded;
@@ -251,6 +255,9 @@ static musica_ctx* make_view(const musica_ctx* c, int i0, int nb) {
     v->d_luts += o * MUSICA_COARSER_LEVELS_START;
     v->d_cnr += o * c->lv[MUSICA_CNR_LEVEL].plane;
     v->d_grad_hist += o * MUSICA_GRAD_BINS;
+    v->d_grad_hist_b += o * MUSICA_GRAD_BINS;
+    v->d_gzero += o;
+    v->d_thr090 += o;
     v->d_grad_max += o;
     v->d_gcurve += o;
     v->d_graded += o * c->lv[0].plane;
@@ -409,6 +416,10 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->graph_input = nullptr;
     c->fuse_u16 = env_int("MUSICA_U16", 1) != 0 && (N % 8) == 0 && !(params->flags & MUSICA_FLAG_GENERIC_KERNELS);
     c->norm_valid = false;
+    // fused gradation histogram: streaming level-0 kernels on raw pixels, cnr scale 8 (every N >= 57 with N % 8 == 0), no CLAHE
+    // block (it wants the stored relevant image anyway)
+    c->fuse_gh = env_int("MUSICA_FUSE_GH", 1) != 0 && c->fuse_u16 && !(params->flags & MUSICA_FLAG_CLAHE) &&
+                 cnr_scale(c->lv[0].S, c->lv[MUSICA_CNR_LEVEL].S) == 8;
     ok = ok && dalloc(c, &c->d_input, B * N * N);
     ok = ok && dalloc(c, &c->d_minmax, B * kMinMaxStride);
     ok = ok && dalloc(c, &c->d_norm, B * c->lv[0].plane);
@@ -425,6 +436,9 @@ static musica_ctx* create_impl(const musica_params* params) {
     ok = ok && dalloc(c, &c->d_cparams, (size_t)L);
     ok = ok && dalloc(c, &c->d_cnr, B * c->lv[MUSICA_CNR_LEVEL].plane);
     ok = ok && dalloc(c, &c->d_grad_hist, B * MUSICA_GRAD_BINS);
+    ok = ok && dalloc(c, &c->d_grad_hist_b, B * MUSICA_GRAD_BINS);
+    ok = ok && dalloc(c, &c->d_gzero, B);
+    ok = ok && dalloc(c, &c->d_thr090, B);
     ok = ok && dalloc(c, &c->d_grad_max, B);
     ok = ok && dalloc(c, &c->d_gcurve, B);
     ok = ok && dalloc(c, &c->d_graded, B * c->lv[0].plane);
@@ -472,6 +486,7 @@ static musica_ctx* create_impl(const musica_params* params) {
 uint32_t musica_get_image_size(const musica_ctx* c) { return c ? (uint32_t)c->N : 0; }
 uint32_t musica_get_levels(const musica_ctx* c) { return c ? (uint32_t)c->L : 0; }
 uint32_t musica_get_batch(const musica_ctx* c) { return c ? (uint32_t)c->B : 0; }
+int musica_fuses_gradation_histogram(const musica_ctx* c) { return (c && c->fuse_gh && !c->generic) ? 1 : 0; }
 uint32_t musica_get_level_size(const musica_ctx* c, uint32_t level) { return (c && (int)level <= c->L) ? (uint32_t)c->lv[level].S : 0; }
 
 }  // extern "C"
@@ -575,7 +590,8 @@ static void enqueue_analysis(musica_ctx* c) {
     }
     {
         Span sp(c, MUSICA_KERNEL_CURVES);
-        launch_noise_curves(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts);
+        launch_noise_curves(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts, c->d_minmax,
+                            c->min_chain_exact, c->d_thr090);
     }
     {
         Span sp(c, MUSICA_KERNEL_CNR);
@@ -604,27 +620,36 @@ static ExpandArgs expand_args(musica_ctx* c, int lvl, float* dst) {
     const musica_nr_params& q = c->h_nr[lvl < 3 ? lvl : 0];
     a.lowCnr = q.lowCnr; a.lowFactor = q.lowFactor; a.highCnr = q.highCnr; a.highFactor = q.highFactor;
     a.rows_per_wave = c->rows_expand[lvl];
+    a.raw = nullptr; a.ghist = nullptr; a.gzero = nullptr; a.thr090 = nullptr;
     return a;
 }
 static int gain_mode(int lvl) { return lvl > MUSICA_CNR_LEVEL ? GAIN_CONST : (lvl == MUSICA_CNR_LEVEL ? GAIN_RANGE : GAIN_CURVE); }
 static bool uses_nr(int lvl) { return lvl < MUSICA_CNR_LEVEL - 1; }  // currentLevel < cnrLevel - 1, src/vk_processing.cpp:1009-1016
 
-static void run_expand_level(musica_ctx* c, int lvl, int rows) {
+// with_hist: the level-0 launch of a fusing context also accumulates the gradation histogram (enqueue_gradation(c, true) must follow)
+static void run_expand_level_h(musica_ctx* c, int lvl, int rows, bool with_hist) {
     ExpandArgs a = expand_args(c, lvl, c->d_recon[lvl]);
     a.rows_per_wave = rows;
+    if (with_hist && lvl == 0 && c->fuse_gh && !c->generic) {
+        a.raw = c->cur_input; a.ghist = c->d_grad_hist; a.gzero = c->d_gzero; a.thr090 = c->d_thr090;
+    }
     launch_expand(c->cur, a, gain_mode(lvl), uses_nr(lvl), c->B, c->generic, c->expand_trip);
 }
+static void run_expand_level(musica_ctx* c, int lvl, int rows) { run_expand_level_h(c, lvl, rows, true); }
 
 // stages "aply" + "exp" (src/vk_processing.cpp:2361-2431)
-static void enqueue_expand(musica_ctx* c) {
+static void enqueue_expand(musica_ctx* c, bool with_hist) {
     for (int lvl = c->L - 1; lvl >= 0; lvl--) {
         Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
-        run_expand_level(c, lvl, c->rows_expand[lvl]);
+        run_expand_level_h(c, lvl, c->rows_expand[lvl], with_hist);
     }
 }
 
 // stage "grad" (src/vk_processing.cpp:2456-2518)
-static void enqueue_gradation(musica_ctx* c) {
+// fused: the level-0 expand launch has already accumulated the histogram (run_expand_level_h with_hist); what is left of K18 + K19 is
+// the literal recount of images that hold an exact zero (a launch that returns at once for every other image).
+static void enqueue_gradation(musica_ctx* c, bool fused) {
+    fused = fused && c->fuse_gh && !c->generic;
     const LevelDesc& l0 = c->lv[0];
     const LevelDesc& l3 = c->lv[MUSICA_CNR_LEVEL];
     const int scale = (int)cnr_scale(l0.S, l3.S);
@@ -635,7 +660,8 @@ static void enqueue_gradation(musica_ctx* c) {
     {
         Span sp(c, MUSICA_KERNEL_GRAD_HIST);
         GradArgs g;
-        g.img = c->d_recon[0]; g.normalized = c->d_norm; g.cnr = c->d_cnr; g.hist = c->d_grad_hist;
+        g.img = c->d_recon[0]; g.normalized = c->d_norm; g.cnr = c->d_cnr; g.hist = fused ? c->d_grad_hist_b : c->d_grad_hist;
+        g.only_if = fused ? c->d_gzero : nullptr;
         g.N = l0.S; g.pitch = l0.pitch; g.plane = l0.plane;
         g.cnrS = l3.S; g.cnrPitch = l3.pitch; g.cnrPlane = l3.plane; g.cnrScale = scale;
         g.groups_per_wave = c->grad_groups;
@@ -644,7 +670,10 @@ static void enqueue_gradation(musica_ctx* c) {
         g.min_chain_exact = c->min_chain_exact;
         launch_grad_hist(c->stream, g, c->B);
     }
-    { Span sp(c, MUSICA_KERNEL_GRAD_CURVE); launch_grad_curve(c->stream, c->d_grad_hist, c->d_grad_max, c->d_gcurve, c->B); }
+    {
+        Span sp(c, MUSICA_KERNEL_GRAD_CURVE);
+        launch_grad_curve(c->stream, c->d_grad_hist, c->d_grad_max, c->d_gcurve, c->B, fused ? c->d_grad_hist_b : nullptr, fused ? c->d_gzero : nullptr);
+    }
     { Span sp(c, MUSICA_KERNEL_GRAD_APPLY); launch_grad_apply(c->stream, c->d_recon[0], c->d_graded, l0, c->d_gcurve, c->B); }
 }
 
@@ -656,7 +685,7 @@ static void enqueue_gradation(musica_ctx* c) {
 static void enqueue_dag(musica_ctx* c) {
     const int L = c->L;
     c->cur = c->stream;
-    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B);  // :2153-2162
+    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B, c->d_grad_hist_b, c->d_gzero);  // :2153-2162
     enqueue_norm(c);
     { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_level(c, 0, c->rows_reduce[0]); }
     { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, 1, c->rows_reduce[1]); }
@@ -691,13 +720,13 @@ static void enqueue_dag(musica_ctx* c) {
     {   // curves of every level + cnr of level 3 in one launch (kernels_analysis.hip k_curves_cnr)
         Span sp(c, MUSICA_KERNEL_CURVES);
         launch_curves_cnr(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
-                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL]);
+                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_thr090);
     }
     for (int lvl = MUSICA_CNR_LEVEL - 1; lvl >= 0; lvl--) {
         Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
         run_expand_level(c, lvl, c->rows_expand[lvl]);
     }
-    enqueue_gradation(c);
+    enqueue_gradation(c, true);
 }
 
 // Per-level form of the dispatch script (dag == 2): the only true dependences are
@@ -710,7 +739,7 @@ static void enqueue_dag(musica_ctx* c) {
 static void enqueue_dag_levels(musica_ctx* c) {
     const int L = c->L;
     c->cur = c->stream;
-    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B);  // :2153-2162
+    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B, c->d_grad_hist_b, c->d_gzero);  // :2153-2162
     enqueue_norm(c);
     for (int i = 0; i < L; i++) {
         c->cur = c->stream;
@@ -735,13 +764,13 @@ static void enqueue_dag_levels(musica_ctx* c) {
     {   // curves of every level + cnr of level 3 in one launch (kernels_analysis.hip k_curves_cnr)
         Span sp(c, MUSICA_KERNEL_CURVES);
         launch_curves_cnr(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
-                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL]);
+                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_thr090);
     }
     for (int lvl = MUSICA_CNR_LEVEL - 1; lvl >= 0; lvl--) {
         Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
         run_expand_level(c, lvl, c->rows_expand[lvl]);
     }
-    enqueue_gradation(c);
+    enqueue_gradation(c, true);
 }
 
 static void enqueue_dag_any(musica_ctx* c) {
@@ -809,12 +838,12 @@ static int enqueue_all(musica_ctx* c) {
         return 1;
     }
     c->cur = c->stream;
-    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B);  // :2153-2162
+    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B, c->d_grad_hist_b, c->d_gzero);  // :2153-2162
     enqueue_norm(c);
     enqueue_reduce(c);
     enqueue_analysis(c);
-    enqueue_expand(c);
-    enqueue_gradation(c);
+    enqueue_expand(c, true);
+    enqueue_gradation(c, true);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e));
     return 1;
@@ -963,10 +992,10 @@ int musica_debug_run_stage(musica_ctx* c, musica_stage stage) {
             launch_clear(c->stream, nullptr, c->d_noise_hist, nullptr, nullptr, c->B);
             enqueue_analysis(c);
             break;
-        case MUSICA_STAGE_EXPAND: enqueue_expand(c); break;
+        case MUSICA_STAGE_EXPAND: enqueue_expand(c, false); break;
         case MUSICA_STAGE_GRADATION:
-            launch_clear(c->stream, nullptr, nullptr, c->d_grad_hist, c->d_clahe_hist, c->B);
-            enqueue_gradation(c);
+            launch_clear(c->stream, nullptr, nullptr, c->d_grad_hist, c->d_clahe_hist, c->B, c->d_grad_hist_b, c->d_gzero);
+            enqueue_gradation(c, false);
             break;
         default: return fail("musica_debug_run_stage: unknown stage %d", (int)stage);
     }

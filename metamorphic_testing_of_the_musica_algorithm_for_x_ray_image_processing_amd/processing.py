@@ -98,6 +98,7 @@ ABI = {
     "musica_get_levels": (C.c_uint32, [_VP]),
     "musica_get_batch": (C.c_uint32, [_VP]),
     "musica_get_level_size": (C.c_uint32, [_VP, C.c_uint32]),
+    "musica_fuses_gradation_histogram": (C.c_int, [_VP]),
     "musica_execute": (C.c_int, [_VP, _U16P]),
     "musica_execute_device": (C.c_int, [_VP, _VP]),
     "musica_upload": (C.c_int, [_VP, _U16P]),
@@ -353,7 +354,7 @@ class MusicaProcessing:
 
     def fuses_gradhist(self):
         """True when the level-0 expand kernel also accumulates the gradation histogram (no separate k_grad_hist launch)."""
-        return False
+        return self._lib.musica_fuses_gradation_histogram(self._h) == 1
 
     # ---- profiling ----------------------------------------------------------------------
     def profile_enable(self, which=True):

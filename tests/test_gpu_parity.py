@@ -185,7 +185,8 @@ def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
             p.cleanup()
 
 
-@pytest.mark.parametrize("env", [{"MUSICA_BAND_TRIP": "1"}, {"MUSICA_EXPAND_TRIP": "2"}, {"MUSICA_U16": "0"},
+@pytest.mark.parametrize("env", [{"MUSICA_BAND_TRIP": "1"}, {"MUSICA_EXPAND_TRIP": "2"}, {"MUSICA_U16": "0"}, {"MUSICA_FUSE_GH": "0"}, {"MUSICA_GH_OCC": "3"},
+                                 {"MUSICA_FUSE_GH": "1", "MUSICA_EXPAND_TRIP": "2"},
                                  {"MUSICA_AUTOTUNE": "0", "MUSICA_REDUCE_ROWS": "4", "MUSICA_BAND_ROWS": "2", "MUSICA_EXPAND_ROWS": "2", "MUSICA_SDEV_ROWS": "16"},
                                  {"MUSICA_AUTOTUNE": "0", "MUSICA_REDUCE_ROWS": "32", "MUSICA_BAND_ROWS": "16", "MUSICA_EXPAND_ROWS": "16", "MUSICA_SDEV_ROWS": "64", "MUSICA_MIN_WAVES": "1"}],
                          ids=lambda e: ",".join("%s=%s" % (k[7:], v) for k, v in e.items()))
@@ -200,6 +201,36 @@ def test_kernel_variants_and_launch_geometries_give_the_same_bits(ob, env, monke
     p = _proc(n, levels)
     assert p.execute(px)
     _compare_all(p, o, ob, tag=str(env) + ": ")
+    p.cleanup()
+
+
+@pytest.mark.parametrize("dag", ["0", "1", "2"])
+def test_exact_zeros_in_the_reconstruction_take_the_literal_histogram(ob, dag, monkeypatch):
+    """A collimated image (test/metamorphic_test/script.py's collimator alteration blacks out a frame): raw zeros give
+    normalized 0, band 0 and — far enough inside — a reconstruction that is exactly 0, where the reference's histogram
+    thread `return`s (gradation_histogram.comp:24) and the noise histogram `break`s (noise_hist.comp:29). The level-0
+    expand kernel that bins on the fly must hand such an image to the literal kernel; an image of the same batch
+    without zeros keeps the fused count. Frame edges are not multiples of 16, so areas with texels on both sides exist."""
+    monkeypatch.setenv("MUSICA_DAG", dag)
+    n, levels = 1024, 4
+    a = phantom(n, 61)
+    a[:203, :] = 0
+    a[:, :187] = 0
+    a[-230:, :] = 0
+    b = phantom(n, 62)
+    px = np.stack([a, b])
+    p = _proc(n, levels, batch=2)
+    assert p.fuses_gradhist()
+    for rep in range(2):
+        assert p.execute(px)
+    for k in range(2):
+        o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[k])
+        if k == 0:
+            assert (o.image(ob.IMG_EXPAND, 0) == 0.0).sum() > 1000
+        _compare_all(p, o, ob, idx=k, tag="zeros image %d: " % k)
+    assert p.execute(px[::-1].copy())           # the flag is per image and re-armed per execute
+    o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[1])
+    _compare_all(p, o, ob, idx=0, tag="swapped: ")
     p.cleanup()
 
 
