@@ -440,8 +440,8 @@ __global__ __launch_bounds__(256) void k_noise_curves(const uint32_t* __restrict
                                                       musica_hist_max_point* __restrict__ maxpts, DevCurve* __restrict__ curves,
                                                       const musica_contrast_params* __restrict__ cparams, int levels,
                                                       DevCurveLut* __restrict__ luts, const uint32_t* __restrict__ minmax, int min_chain_exact,
-                                                      int* __restrict__ thr090) {
-    noise_curves_block(blockIdx.x, blockIdx.y, hist, hist_stride, maxpts, curves, cparams, levels, luts, minmax, min_chain_exact, thr090);
+                                                      int* __restrict__ thr090, int lev0) {
+    noise_curves_block(lev0 + (int)blockIdx.x, blockIdx.y, hist, hist_stride, maxpts, curves, cparams, levels, luts, minmax, min_chain_exact, thr090);
 }
 
 // K12 + K13 and K15 in one launch: workgroups 0 .. levels-1 of an image build that level's curve, the others each
@@ -453,10 +453,12 @@ __global__ __launch_bounds__(256) void k_curves_cnr(const uint32_t* __restrict__
                                                     const musica_contrast_params* __restrict__ cparams, int levels,
                                                     DevCurveLut* __restrict__ luts, const float* __restrict__ sdev, float* __restrict__ cnr,
                                                     int S, int pitch, size_t plane, int tiles_x, const uint32_t* __restrict__ minmax,
-                                                    int min_chain_exact, int* __restrict__ thr090) {
+                                                    int min_chain_exact, int* __restrict__ thr090, int lev0) {
+    // workgroups 0 .. levels-lev0-1 build the curves of levels lev0 .. levels-1 (lev0 = 1 when level 0 has a launch of its own)
     const int img = blockIdx.y;
-    if ((int)blockIdx.x < levels) {   // block-uniform
-        noise_curves_block(blockIdx.x, img, hist, hist_stride, maxpts, curves, cparams, levels, luts, minmax, min_chain_exact, thr090);
+    const int nlev = levels - lev0;
+    if ((int)blockIdx.x < nlev) {   // block-uniform
+        noise_curves_block(lev0 + (int)blockIdx.x, img, hist, hist_stride, maxpts, curves, cparams, levels, luts, minmax, min_chain_exact, thr090);
         return;
     }
     __shared__ unsigned long long scratch2[16];
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(256) void k_curves_cnr(const uint32_t* __restrict__
     const uint32_t maxBin = k ? 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull) : 0u;
     float ref = (float)maxBin * (1.0f / (float)MUSICA_NOISE_BINS) * kMaxNoiseValue;            // img_cnr.comp:22
     if (ref == 0.0f) ref = (1.0f / (float)MUSICA_NOISE_BINS) * kMaxNoiseValue;                  // :25
-    const int t = (int)blockIdx.x - levels;
+    const int t = (int)blockIdx.x - nlev;
     const int x = (t % tiles_x) * 32 + (int)(threadIdx.x & 31), y = (t / tiles_x) * 8 + (int)(threadIdx.x >> 5);
     if (x >= S || y >= S) return;
     const size_t o = (size_t)img * plane + (size_t)y * pitch + x;
@@ -586,7 +588,7 @@ void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const Leve
     else if (dbg == 3) hipLaunchKernelGGL((k_sdev_hist<2, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
     else if (dbg == 5) hipLaunchKernelGGL((k_sdev_hist_pf<false>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
     else if (dbg == 4) hipLaunchKernelGGL((k_sdev_hist<4, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
-    else hipLaunchKernelGGL((k_sdev_hist_pf<true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
+    else hipLaunchKernelGGL((k_sdev_hist_pf<true>), grid, dim3(kBlockThreads), l.S >= 2048 ? l0_lds_pad() : 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
 }
 
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch) {
@@ -596,17 +598,17 @@ void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& 
 
 void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves,
                          const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const uint32_t* minmax, int min_chain_exact,
-                         int* thr090) {
-    hipLaunchKernelGGL(k_noise_curves, dim3(levels, batch), dim3(256), 0, st, hist, hist_stride, maxpts, curves, cparams, levels, luts, minmax,
-                       min_chain_exact, thr090);
+                         int* thr090, int lev0, int nlev) {
+    hipLaunchKernelGGL(k_noise_curves, dim3(nlev > 0 ? nlev : levels - lev0, batch), dim3(256), 0, st, hist, hist_stride, maxpts, curves, cparams, levels, luts,
+                       minmax, min_chain_exact, thr090, lev0);
 }
 
 void launch_curves_cnr(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves,
                        const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const float* sdev, float* cnr,
-                       const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact, int* thr090) {
+                       const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact, int* thr090, int lev0) {
     const int tiles_x = (l3.S + 31) / 32, tiles_y = (l3.S + 7) / 8;
-    hipLaunchKernelGGL(k_curves_cnr, dim3(levels + tiles_x * tiles_y, batch), dim3(256), 0, st, hist, hist_stride, maxpts, curves, cparams, levels,
-                       luts, sdev, cnr, l3.S, l3.pitch, l3.plane, tiles_x, minmax, min_chain_exact, thr090);
+    hipLaunchKernelGGL(k_curves_cnr, dim3(levels - lev0 + tiles_x * tiles_y, batch), dim3(256), 0, st, hist, hist_stride, maxpts, curves, cparams, levels,
+                       luts, sdev, cnr, l3.S, l3.pitch, l3.plane, tiles_x, minmax, min_chain_exact, thr090, lev0);
 }
 
 void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& l3, const musica_hist_max_point* maxpts, int levels,

@@ -778,9 +778,9 @@ void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, fl
     const dim3 grid = stream_grid(lf.S, lc.S, rows_per_wave, batch);
     const float* fine = reinterpret_cast<const float*>(px);
     if (rows_per_trip >= 2)
-        hipLaunchKernelGGL((k_band_fast<2, true>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
+        hipLaunchKernelGGL((k_band_fast<2, true>), grid, dim3(kBlockThreads), l0_lds_pad(), st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
     else
-        hipLaunchKernelGGL((k_band_fast<1, true>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
+        hipLaunchKernelGGL((k_band_fast<1, true>), grid, dim3(kBlockThreads), l0_lds_pad(), st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
 }
 
 void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc,

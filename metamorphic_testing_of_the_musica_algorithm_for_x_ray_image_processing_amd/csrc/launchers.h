@@ -2,6 +2,7 @@
 // argument blocks they share with the dispatch script in musica_ctx.hip.
 #pragma once
 
+#include <stdlib.h>
 #include "musica_device.h"
 
 namespace musica {
@@ -55,6 +56,8 @@ struct GradArgs {
     const uint32_t* only_if; // non-NULL: images whose word is 0 are skipped (fix-up launch behind the fused expand kernel)
 };
 
+// experiment: dynamic LDS bytes added to the level-0 band / sdev launches (caps their workgroups per CU, leaving wave slots free)
+static inline unsigned l0_lds_pad() { static const int v = getenv("MUSICA_L0_LDS_PAD") ? atoi(getenv("MUSICA_L0_LDS_PAD")) : 0; return (unsigned)v; }
 // kernels_pyramid.hip
 void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave, bool force_generic, int tag);
 void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave, bool force_generic, int rows_per_trip);
@@ -72,10 +75,10 @@ void launch_normalize(hipStream_t st, const uint16_t* px, float* out, const Leve
 void launch_sqrt(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, int batch);
 void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch, int rows_per_wave);
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch);
-void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves, const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const uint32_t* minmax, int min_chain_exact, int* thr090);
+void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves, const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const uint32_t* minmax, int min_chain_exact, int* thr090, int lev0 = 0, int nlev = 0);
 void launch_curves_cnr(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves,
                        const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const float* sdev, float* cnr,
-                       const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact, int* thr090);
+                       const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact, int* thr090, int lev0 = 0);
 void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& l3, const musica_hist_max_point* maxpts, int levels, int batch);
 void launch_selftest_exact_math(hipStream_t st, unsigned long long* d_bad4);
 void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact,

@@ -65,6 +65,8 @@ struct musica_ctx {
     hipStream_t cur;         // stream the run_*_level helpers launch on (stream or side)
     hipStream_t side;        // coarse-level chain runs here, concurrently with the level-0 kernels on `stream`
     hipEvent_t ev_fork, ev_join;
+    hipStream_t side1;       // dag == 3: level 1 (band, sdev, then curves + expand 2, 1) beside level 0 on `stream` and levels >= 2 on `side`
+    hipEvent_t ev_s1, ev_s2;
     // per-level dispatch (dag == 2): band + sdev of level i run on lvs[i] as soon as reduce i is done
     hipStream_t lvs[MUSICA_MAX_LEVELS];
     hipEvent_t ev_r[MUSICA_MAX_LEVELS], ev_l[MUSICA_MAX_LEVELS];
@@ -75,7 +77,8 @@ struct musica_ctx {
     bool use_graph;
     hipGraphExec_t graph_exec;
     const uint16_t* graph_input;
-    int dag;                 // 0: one in-order stream; 1: two streams (levels 0-1 | coarse chain); 2: one stream per level
+    int dag;                 // 0: one in-order stream; 1: two streams (levels 0-1 | coarse chain); 2: one stream per level;
+                             // 3: three streams (level 0 | level 1 + curve-dependent expands | levels >= 2)
     // device state
     uint16_t* d_input;
     const uint16_t* cur_input;
@@ -233,7 +236,7 @@ static musica_ctx* make_view(const musica_ctx* c, int i0, int nb) {
     v->spans.clear();
     v->spans_used = 0;
     v->views.clear();
-    v->stream = nullptr; v->side = nullptr; v->ev_fork = nullptr; v->ev_join = nullptr; v->ev_gfork = nullptr; v->ev_gdone = nullptr;
+    v->stream = nullptr; v->side = nullptr; v->side1 = nullptr; v->ev_s1 = nullptr; v->ev_s2 = nullptr; v->ev_fork = nullptr; v->ev_join = nullptr; v->ev_gfork = nullptr; v->ev_gdone = nullptr;
     v->graph_exec = nullptr; v->graph_input = nullptr;   // every group captures and replays its own graph
     v->first_image = i0;
     v->B = nb;
@@ -286,6 +289,9 @@ static bool make_views(musica_ctx* c, int groups) {
         c->views.push_back(v);
         ok = ok && hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipStreamCreateWithFlags(&v->side, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&v->side1, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&v->ev_s1, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&v->ev_s2, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&v->ev_gdone, hipEventDisableTiming) == hipSuccess;
@@ -314,6 +320,9 @@ void musica_destroy(musica_ctx* c) {
         for (auto& s : v->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
         if (v->stream) { hipStreamSynchronize(v->stream); hipStreamDestroy(v->stream); }
         if (v->side) { hipStreamSynchronize(v->side); hipStreamDestroy(v->side); }
+        if (v->side1) { hipStreamSynchronize(v->side1); hipStreamDestroy(v->side1); }
+        if (v->ev_s1) hipEventDestroy(v->ev_s1);
+        if (v->ev_s2) hipEventDestroy(v->ev_s2);
         if (v->ev_fork) hipEventDestroy(v->ev_fork);
         if (v->ev_join) hipEventDestroy(v->ev_join);
         if (v->ev_gdone) hipEventDestroy(v->ev_gdone);
@@ -327,6 +336,9 @@ void musica_destroy(musica_ctx* c) {
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
     destroy_level_streams(c);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    if (c->side1) { hipStreamSynchronize(c->side1); hipStreamDestroy(c->side1); }
+    if (c->ev_s1) hipEventDestroy(c->ev_s1);
+    if (c->ev_s2) hipEventDestroy(c->ev_s2);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -372,7 +384,7 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->p.levels = L; c->p.batch = (uint32_t)c->B;
     c->generic = (params->flags & MUSICA_FLAG_GENERIC_KERNELS) != 0;
     c->tuning = false;
-    c->stream = nullptr; c->side = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr; c->profiling = 0; c->spans_used = 0; c->cur_input = nullptr;
+    c->stream = nullptr; c->side = nullptr; c->side1 = nullptr; c->ev_s1 = nullptr; c->ev_s2 = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr; c->profiling = 0; c->spans_used = 0; c->cur_input = nullptr;
     c->ev_gfork = nullptr; c->ev_gdone = nullptr; c->first_image = 0;
     memset(c->prof_total_us, 0, sizeof(c->prof_total_us));
     memset(c->prof_count, 0, sizeof(c->prof_count));
@@ -404,11 +416,14 @@ static musica_ctx* create_impl(const musica_params* params) {
     ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->side1, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_s1, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_s2, hipEventDisableTiming) == hipSuccess;
     // little work per step (<= 8 Mpixel): the per-level form wins (one 2048^2 image: 0.229 vs 0.241 ms, shorter dependent
     // chain); more: the two-stream form (8 x 2048^2: 0.564 vs 0.571 ms; one 8192^2: 1.05 vs 1.11 ms — the reduce chain
     // of the per-level form crawls among the big kernels, and running the whole reduce chain first costs 0.69 ms)
     c->dag = env_int("MUSICA_DAG", (size_t)c->B * N * N <= ((size_t)8 << 20) ? 2 : 1);
-    if (c->dag < 0 || c->dag > 2) c->dag = 1;
+    if (c->dag < 0 || c->dag > 3) c->dag = 1;
     for (int i = 0; i < MUSICA_MAX_LEVELS; i++) { c->lvs[i] = nullptr; c->ev_r[i] = nullptr; c->ev_l[i] = nullptr; }
     ok = ok && create_level_streams(c);
     c->use_graph = c->dag && !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", 1) != 0;
@@ -773,8 +788,71 @@ static void enqueue_dag_levels(musica_ctx* c) {
     enqueue_gradation(c, true);
 }
 
+// Three-stream form (dag == 3). What starts the biggest kernel of the tail — expand of level 0, then the gradation stage — is
+// (a) the level-0 curve, i.e. sdev 0, and (b) the reconstruction of level 1. In the two-stream form (b) only starts after sdev 0
+// (band 1, sdev 1, curves, expand 2, expand 1: ~140 us of kernels that each fill a fraction of the chip). Here level 1 has a stream
+// of its own next to level 0, the curves of levels >= 1 (+ cnr) are generated as soon as their histograms exist, and level 0
+// gets a one-workgroup-per-image curve launch of its own behind sdev 0:
+//   stream : clear minmax R0 R1 | B0 S0 curve0 ......................... (wait side1) E0 gradation
+//   side1  :                    | B1 S1 (wait side) curves1..L-1+cnr E2 E1
+//   side   :                    | R2 B2 S2 R3 B3 S3 R4 B4 ... E(L-1) .. E3
+// Capture order = issue order (a replay enqueues its nodes in capture order, a few microseconds each): level 0 first — band 0 is
+// the long pole and the dozen small launches of the side chains are enqueued while it runs.
+static void enqueue_dag3(musica_ctx* c) {
+    const int L = c->L;
+    c->cur = c->stream;
+    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B, c->d_grad_hist_b, c->d_gzero);  // :2153-2162
+    enqueue_norm(c);
+    { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_level(c, 0, c->rows_reduce[0]); }
+    { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, 1, c->rows_reduce[1]); }
+    hipEventRecord(c->ev_fork, c->stream);
+    hipStreamWaitEvent(c->side, c->ev_fork, 0);
+    hipStreamWaitEvent(c->side1, c->ev_fork, 0);
+    // level 0
+    c->cur = c->stream;
+    { Span sp(c, MUSICA_KERNEL_BAND_L0); run_band_level(c, 0, c->rows_band[0]); }
+    { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, 0, c->rows_sdev[0]); }
+    {
+        Span sp(c, MUSICA_KERNEL_CURVES);
+        launch_noise_curves(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
+                            c->d_minmax, c->min_chain_exact, nullptr, 0, 1);
+    }
+    // levels >= 2: nothing here needs a histogram-derived curve (constant gain above level 3, range gain at level 3)
+    c->cur = c->side;
+    for (int i = 2; i < L; i++) {
+        { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
+        { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
+        if (i <= MUSICA_CNR_LEVEL) { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
+    }
+    for (int lvl = L - 1; lvl >= MUSICA_CNR_LEVEL; lvl--) {
+        Span sp(c, MUSICA_KERNEL_EXPAND_REST);
+        run_expand_level(c, lvl, c->rows_expand[lvl]);
+    }
+    hipEventRecord(c->ev_s2, c->side);
+    // level 1, then everything of levels 2 and 1 that needs a curve
+    c->cur = c->side1;
+    { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, 1, c->rows_band[1]); }
+    { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, 1, c->rows_sdev[1]); }
+    hipStreamWaitEvent(c->side1, c->ev_s2, 0);
+    {
+        Span sp(c, MUSICA_KERNEL_CURVES);
+        launch_curves_cnr(c->side1, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
+                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_thr090, 1);
+    }
+    for (int lvl = MUSICA_CNR_LEVEL - 1; lvl >= 1; lvl--) {
+        Span sp(c, MUSICA_KERNEL_EXPAND_REST);
+        run_expand_level(c, lvl, c->rows_expand[lvl]);
+    }
+    hipEventRecord(c->ev_s1, c->side1);
+    c->cur = c->stream;
+    hipStreamWaitEvent(c->stream, c->ev_s1, 0);
+    { Span sp(c, MUSICA_KERNEL_EXPAND_L0); run_expand_level(c, 0, c->rows_expand[0]); }
+    enqueue_gradation(c, true);
+}
+
 static void enqueue_dag_any(musica_ctx* c) {
-    if (c->dag == 2) enqueue_dag_levels(c);
+    if (c->dag == 3) enqueue_dag3(c);
+    else if (c->dag == 2) enqueue_dag_levels(c);
     else enqueue_dag(c);
 }
 

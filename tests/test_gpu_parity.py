@@ -174,7 +174,7 @@ def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
     n, levels = 1032, 6
     px = np.stack([phantom(n, 800 + k) for k in range(batch)])
     want = [ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[k]) for k in range(batch)]
-    for dag in ("0", "1", "2"):
+    for dag in ("0", "1", "2", "3"):
         for flags in (0, mp.FLAG_NO_GRAPH):
             monkeypatch.setenv("MUSICA_DAG", dag)
             p = _proc(n, levels, batch=batch, flags=flags)
@@ -204,7 +204,7 @@ def test_kernel_variants_and_launch_geometries_give_the_same_bits(ob, env, monke
     p.cleanup()
 
 
-@pytest.mark.parametrize("dag", ["0", "1", "2"])
+@pytest.mark.parametrize("dag", ["0", "1", "2", "3"])
 def test_exact_zeros_in_the_reconstruction_take_the_literal_histogram(ob, dag, monkeypatch):
     """A collimated image (test/metamorphic_test/script.py's collimator alteration blacks out a frame): raw zeros give
     normalized 0, band 0 and — far enough inside — a reconstruction that is exactly 0, where the reference's histogram
