@@ -236,6 +236,17 @@ int musica_debug_process(musica_ctx* ctx, uint32_t image_index, const char* dir)
 
 /* ---- test / profiling hooks ------------------------------------------ */
 
+/* A sequence of `count` batches (pixels[j]: batch x N x N uint16 in host memory), pipelined: two device input buffers and a
+ * copy stream, so the host-to-device copy of batch j + 1 runs under the kernels of batch j — what replaces the reference's
+ * staging-buffer upload with three queue-idle waits per image (VulkanState::loadDataToImage, src/vk_state.cpp:313-342).
+ * Returns after the last batch has been computed; the context then holds the results of batch count - 1 (every getter works).
+ * stats (may be NULL): count * batch rows, row j * batch + i = image i of batch j, image_id = its index in the sequence.
+ * Inputs in pinned memory (musica_host_alloc) are copied at the PCIe rate; pageable memory is accepted (slower). */
+int musica_execute_stream(musica_ctx* ctx, const uint16_t* const* pixels, uint32_t count, musica_stats* stats);
+/* Page-locked host memory for musica_execute_stream / musica_execute inputs (hipHostMalloc / hipHostFree). */
+void* musica_host_alloc(musica_ctx* ctx, size_t bytes);
+void musica_host_free(musica_ctx* ctx, void* ptr);
+
 /* Overwrites one stored intermediate of one batch entry (dense f32 in). Only
  * kinds the hot path keeps resident are accepted. */
 int musica_debug_set_image(musica_ctx* ctx, uint32_t image_index, musica_image_kind kind, uint32_t level, const float* src);

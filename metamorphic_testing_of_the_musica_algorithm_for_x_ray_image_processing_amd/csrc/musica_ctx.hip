@@ -75,12 +75,16 @@ struct musica_ctx {
     // hipGraph replay of the two-stream dispatch (captured once per input pointer; MUSICA_FLAG_NO_GRAPH /
     // MUSICA_GRAPH=0 / per-kernel profiling fall back to eager launches)
     bool use_graph;
-    hipGraphExec_t graph_exec;
-    const uint16_t* graph_input;
+    hipGraphExec_t graph_exec[2];      // one captured graph per input pointer, the two most recently used (the streaming
+    const uint16_t* graph_input[2];    // path alternates between two device input buffers)
+    int graph_next;                    // slot the next capture overwrites
     int dag;                 // 0: one in-order stream; 1: two streams (levels 0-1 | coarse chain); 2: one stream per level;
                              // 3: three streams (level 0 | level 1 + curve-dependent expands | levels >= 2)
     // device state
     uint16_t* d_input;
+    uint16_t* d_input2;      // second input buffer of the streaming path (musica_execute_stream), allocated on first use
+    hipStream_t copy_stream; // its H2D copies run here, under the previous batch's kernels
+    hipEvent_t ev_copied[2], ev_consumed[2];
     const uint16_t* cur_input;
     uint32_t* d_minmax;
     float* d_norm;
@@ -237,7 +241,7 @@ static musica_ctx* make_view(const musica_ctx* c, int i0, int nb) {
     v->spans_used = 0;
     v->views.clear();
     v->stream = nullptr; v->side = nullptr; v->side1 = nullptr; v->ev_s1 = nullptr; v->ev_s2 = nullptr; v->ev_fork = nullptr; v->ev_join = nullptr; v->ev_gfork = nullptr; v->ev_gdone = nullptr;
-    v->graph_exec = nullptr; v->graph_input = nullptr;   // every group captures and replays its own graph
+    v->graph_exec[0] = v->graph_exec[1] = nullptr; v->graph_input[0] = v->graph_input[1] = nullptr; v->graph_next = 0;   // every group captures and replays its own graphs
     v->first_image = i0;
     v->B = nb;
     v->p.batch = (uint32_t)nb;
@@ -327,13 +331,18 @@ void musica_destroy(musica_ctx* c) {
         if (v->ev_join) hipEventDestroy(v->ev_join);
         if (v->ev_gdone) hipEventDestroy(v->ev_gdone);
         destroy_level_streams(v);
-        if (v->graph_exec) hipGraphExecDestroy(v->graph_exec);
+        for (int k = 0; k < 2; k++) if (v->graph_exec[k]) hipGraphExecDestroy(v->graph_exec[k]);
         delete v;
     }
     if (c->ev_gfork) hipEventDestroy(c->ev_gfork);
+    if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
+    for (int k = 0; k < 2; k++) {
+        if (c->ev_copied[k]) hipEventDestroy(c->ev_copied[k]);
+        if (c->ev_consumed[k]) hipEventDestroy(c->ev_consumed[k]);
+    }
     for (auto& s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (void* p : c->allocations) hipFree(p);
-    if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
+    for (int k = 0; k < 2; k++) if (c->graph_exec[k]) hipGraphExecDestroy(c->graph_exec[k]);
     destroy_level_streams(c);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c->side1) { hipStreamSynchronize(c->side1); hipStreamDestroy(c->side1); }
@@ -386,6 +395,7 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->tuning = false;
     c->stream = nullptr; c->side = nullptr; c->side1 = nullptr; c->ev_s1 = nullptr; c->ev_s2 = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr; c->profiling = 0; c->spans_used = 0; c->cur_input = nullptr;
     c->ev_gfork = nullptr; c->ev_gdone = nullptr; c->first_image = 0;
+    c->d_input2 = nullptr; c->copy_stream = nullptr; c->ev_copied[0] = c->ev_copied[1] = c->ev_consumed[0] = c->ev_consumed[1] = nullptr;
     memset(c->prof_total_us, 0, sizeof(c->prof_total_us));
     memset(c->prof_count, 0, sizeof(c->prof_count));
     int s = (int)N;
@@ -427,8 +437,9 @@ static musica_ctx* create_impl(const musica_params* params) {
     for (int i = 0; i < MUSICA_MAX_LEVELS; i++) { c->lvs[i] = nullptr; c->ev_r[i] = nullptr; c->ev_l[i] = nullptr; }
     ok = ok && create_level_streams(c);
     c->use_graph = c->dag && !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", 1) != 0;
-    c->graph_exec = nullptr;
-    c->graph_input = nullptr;
+    c->graph_exec[0] = c->graph_exec[1] = nullptr;
+    c->graph_input[0] = c->graph_input[1] = nullptr;
+    c->graph_next = 0;
     c->fuse_u16 = env_int("MUSICA_U16", 1) != 0 && (N % 8) == 0 && !(params->flags & MUSICA_FLAG_GENERIC_KERNELS);
     c->norm_valid = false;
     // fused gradation histogram: streaming level-0 kernels on raw pixels, cnr scale 8 (every N >= 57 with N % 8 == 0), no CLAHE
@@ -859,15 +870,16 @@ static void enqueue_dag_any(musica_ctx* c) {
 // Captures enqueue_dag() (both streams: the side stream joins the capture through ev_fork and rejoins
 // through ev_join) into an executable graph for the current input pointer.
 static bool capture_graph(musica_ctx* c) {
-    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    const int k = c->graph_next;
+    if (c->graph_exec[k]) { hipGraphExecDestroy(c->graph_exec[k]); c->graph_exec[k] = nullptr; c->graph_input[k] = nullptr; }
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
     enqueue_dag_any(c);
     if (hipStreamEndCapture(c->stream, &graph) != hipSuccess || !graph) { (void)hipGetLastError(); return false; }
-    const hipError_t e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+    const hipError_t e = hipGraphInstantiate(&c->graph_exec[k], graph, nullptr, nullptr, 0);
     hipGraphDestroy(graph);
-    if (e != hipSuccess) { c->graph_exec = nullptr; (void)hipGetLastError(); return false; }
-    c->graph_input = c->cur_input;
+    if (e != hipSuccess) { c->graph_exec[k] = nullptr; (void)hipGetLastError(); return false; }
+    c->graph_input[k] = c->cur_input;
     return true;
 }
 
@@ -900,12 +912,15 @@ static int enqueue_groups(musica_ctx* c) {
 static int enqueue_all(musica_ctx* c) {
     if (!c->views.empty() && !c->tuning) return enqueue_groups(c);
     if (c->dag && !c->tuning && c->use_graph && c->profiling == 0) {
-        if (!c->graph_exec || c->graph_input != c->cur_input) {
+        int k = (c->graph_exec[0] && c->graph_input[0] == c->cur_input) ? 0 : (c->graph_exec[1] && c->graph_input[1] == c->cur_input) ? 1 : -1;
+        if (k < 0) {
             if (!capture_graph(c)) c->use_graph = false;   // e.g. a runtime without capture support: stay eager
+            else k = c->graph_next;
         }
-        if (c->graph_exec && c->graph_input == c->cur_input) {
+        if (k >= 0) {
+            c->graph_next = k ^ 1;                         // the other slot is now the least recently used
             c->norm_valid = c->d_clahe_hist != nullptr || !c->fuse_u16;
-            if (hipGraphLaunch(c->graph_exec, c->stream) != hipSuccess) return fail("hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError()));
+            if (hipGraphLaunch(c->graph_exec[k], c->stream) != hipSuccess) return fail("hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError()));
             return 1;
         }
     }
@@ -1055,6 +1070,73 @@ int musica_execute(musica_ctx* c, const uint16_t* pixels) {
     c->cur_input = c->d_input;
     if (!enqueue_all(c)) return 0;
     return musica_sync(c);  // vkWaitForFences, src/vk_processing.cpp:2535-2536
+}
+
+// The reference uploads every image through a freshly allocated staging buffer and three queue-idle waits before a single
+// dispatch starts (VulkanState::loadDataToImage, src/vk_state.cpp:313-342). A sequence of batches is pipelined instead: two
+// device input buffers, host-to-device copies on a stream of their own, so the copy of batch j + 1 runs under the kernels of
+// batch j and the host only blocks at the very end. Input in pinned memory (musica_host_alloc) moves at the PCIe rate;
+// pageable memory works too (the runtime stages it, slower and partly synchronous).
+int musica_execute_stream(musica_ctx* c, const uint16_t* const* pixels, uint32_t count, musica_stats* stats) {
+    CHECK_CTX(c);
+    if (!pixels) return fail("musica_execute_stream: pixels is NULL");
+    if (!c->views.empty()) return fail("musica_execute_stream: not available with image groups (MUSICA_GROUPS > 1)");
+    const size_t bytes = (size_t)c->B * c->N * c->N * sizeof(uint16_t);
+    if (!c->d_input2) {
+        if (!dalloc(c, &c->d_input2, (size_t)c->B * c->N * c->N)) return fail("musica_execute_stream: device allocation failed");
+        HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            HIP_OK(hipEventCreateWithFlags(&c->ev_copied[k], hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&c->ev_consumed[k], hipEventDisableTiming));
+        }
+    }
+    musica_stats* d_rows = nullptr;
+    musica_stats* h_rows = nullptr;
+    if (stats) {
+        HIP_OK(hipMalloc(&d_rows, (size_t)count * c->B * sizeof(musica_stats)));
+        if (hipHostMalloc(&h_rows, (size_t)count * c->B * sizeof(musica_stats), hipHostMallocDefault) != hipSuccess) { hipFree(d_rows); return fail("musica_execute_stream: pinned allocation failed"); }
+    }
+    HIP_OK(hipStreamSynchronize(c->stream));   // nothing of an earlier call still reads the input buffers
+    uint16_t* bufs[2] = {c->d_input, c->d_input2};
+    int ok = 1;
+    for (uint32_t j = 0; j < count && ok; j++) {
+        const int k = (int)(j & 1u);
+        if (!pixels[j]) { ok = fail("musica_execute_stream: pixels[%u] is NULL", j); break; }
+        if (j >= 2) hipStreamWaitEvent(c->copy_stream, c->ev_consumed[k], 0);   // batch j - 2 has been computed: its buffer is free
+        if (hipMemcpyAsync(bufs[k], pixels[j], bytes, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) { ok = fail("musica_execute_stream: H2D copy failed"); break; }
+        hipEventRecord(c->ev_copied[k], c->copy_stream);
+        hipStreamWaitEvent(c->stream, c->ev_copied[k], 0);
+        c->cur_input = bufs[k];
+        ok = enqueue_all(c);
+        if (ok && stats) {
+            launch_stats(c->stream, c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_noise_max, c->L, c->d_grad_max, c->d_gcurve,
+                         d_rows + (size_t)j * c->B, j * (uint32_t)c->B, c->B);
+        }
+        hipEventRecord(c->ev_consumed[k], c->stream);
+    }
+    if (ok && stats) ok = hipMemcpyAsync(h_rows, d_rows, (size_t)count * c->B * sizeof(musica_stats), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->copy_stream);
+    if (ok && e == hipSuccess && stats) memcpy(stats, h_rows, (size_t)count * c->B * sizeof(musica_stats));
+    if (d_rows) hipFree(d_rows);
+    if (h_rows) hipHostFree(h_rows);
+    if (e != hipSuccess) return fail("musica_execute_stream: %s", hipGetErrorString(e));
+    if (c->profiling) collect_spans(c);
+    return ok;
+}
+
+void* musica_host_alloc(musica_ctx* c, size_t bytes) {
+    if (!c || hipSetDevice(c->p.device) != hipSuccess) return nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { fail("musica_host_alloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+void musica_host_free(musica_ctx* c, void* p) {
+    if (!c || !p) return;
+    hipSetDevice(c->p.device);
+    hipStreamSynchronize(c->stream);
+    if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
+    hipHostFree(p);
 }
 
 int musica_debug_run_stage(musica_ctx* c, musica_stage stage) {

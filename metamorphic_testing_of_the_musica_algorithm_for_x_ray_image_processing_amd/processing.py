@@ -101,6 +101,9 @@ ABI = {
     "musica_fuses_gradation_histogram": (C.c_int, [_VP]),
     "musica_execute": (C.c_int, [_VP, _U16P]),
     "musica_execute_device": (C.c_int, [_VP, _VP]),
+    "musica_execute_stream": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, C.POINTER(Stats)]),
+    "musica_host_alloc": (_VP, [_VP, C.c_size_t]),
+    "musica_host_free": (None, [_VP, _VP]),
     "musica_upload": (C.c_int, [_VP, _U16P]),
     "musica_input_device_ptr": (_VP, [_VP]),
     "musica_sync": (C.c_int, [_VP]),
@@ -260,6 +263,31 @@ class MusicaProcessing:
 
     def sync(self):
         self._ok(self._lib.musica_sync(self._h), "musica_sync")
+
+    def host_alloc(self, shape, dtype=np.uint16):
+        """A numpy array in page-locked host memory (inputs of execute_stream move at the PCIe rate from it). Free with host_free()."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self._lib.musica_host_alloc(self._h, n)
+        if not p:
+            raise MemoryError(last_error())
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).view(dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p:
+            self._lib.musica_host_free(self._h, p)
+
+    def execute_stream(self, batches, want_stats=False):
+        """Pipelined execute over a list of (batch, N, N) uint16 arrays: H2D of batch j + 1 under the kernels of batch j.
+        Returns True / False, or (ok, [Stats per image of the sequence]) with want_stats."""
+        arrs = [self._pixels(b) for b in batches]
+        ptrs = (_VP * len(arrs))(*[a.ctypes.data for a in arrs])
+        st = (Stats * (len(arrs) * self.batch))() if want_stats else None
+        ok = self._lib.musica_execute_stream(self._h, ptrs, len(arrs), st) == 1
+        return (ok, list(st)) if want_stats else ok
 
     def graded(self):
         n = self.imageSize

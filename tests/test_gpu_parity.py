@@ -234,6 +234,38 @@ def test_exact_zeros_in_the_reconstruction_take_the_literal_histogram(ob, dag, m
     p.cleanup()
 
 
+def test_streaming_execute_overlaps_copies_and_keeps_every_batch_exact(ob):
+    """musica_execute_stream: a sequence of different batches through the two-buffer pipeline (pageable and pinned inputs,
+    odd count so both device buffers and both cached graphs are reused): every image's stats row equals the oracle's, the
+    context ends up holding the last batch, and a plain execute afterwards still works."""
+    n, levels, b, count = 520, 5, 2, 5
+    p = _proc(n, levels, batch=b)
+    seq = [np.stack([phantom(n, 1000 + 10 * j + k) for k in range(b)]) for j in range(count)]
+    pinned = p.host_alloc(seq[1].shape)
+    pinned[...] = seq[1]
+    ok, st = p.execute_stream([seq[0], pinned, seq[2], seq[3], seq[4]], want_stats=True)
+    assert ok, mp.last_error()
+    assert len(st) == count * b
+    for j in range(count):
+        for k in range(b):
+            o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(seq[j][k])
+            got, want = st[j * b + k], o.stats()
+            assert got.image_id == j * b + k
+            assert list(got.noise_max_bin) == list(want.noise_max_bin) and got.grad_max_bin == want.grad_max_bin and got.grad_max_value == want.grad_max_value
+            assert (got.t0, got.ta, got.t1, got.min_sqrt, got.max_sqrt) == (want.t0, want.ta, want.t1, want.min_sqrt, want.max_sqrt)
+            assert abs(got.mean_cnr - want.mean_cnr) <= 1e-5 * max(1.0, abs(want.mean_cnr))
+            if j == count - 1:
+                _compare_all(p, o, ob, idx=k, tag="stream, last batch, image %d: " % k)
+    p.host_free(pinned)
+    assert p.execute_stream([seq[2]])                      # a sequence of one
+    o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(seq[2][1])
+    _same(p.graded()[1], o.image(ob.IMG_GRADED), "graded after a one-batch stream")
+    assert p.execute(seq[0])
+    o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(seq[0][0])
+    _same(p.graded()[0], o.image(ob.IMG_GRADED), "graded after execute")
+    p.cleanup()
+
+
 def _random_cases(count, seed):
     """(N, levels, phantom seed, bits, noise) drawn once from a fixed generator: odd sizes, sizes around the strip
     (512) and vector (8) boundaries, the smallest accepted sides, reference-rule and explicit level counts."""
