@@ -1,6 +1,6 @@
 """Stand-alone metric kernel from HBM (rotating buffers) for a few sizes and rows-per-wavefront choices, with the
 copy-shaped ceiling beside it. Usage: python devtools/sweep_cold.py [side,nbuf ...] [--rows 0,4,8]
-Experiment knobs are read from the environment by the library (MUSICA_REDUCE_D, MUSICA_REDUCE_AUX, MUSICA_COPY_MODE)."""
+"""
 import os
 import sys
 
@@ -13,7 +13,7 @@ for a in sys.argv[1:]:
     if a.startswith("--rows="):
         rows_list = tuple(int(v) for v in a[7:].split(","))
 cases = [tuple(int(v) for v in a.split(",")) for a in args] or [(4096, 8), (2048, 32), (8192, 3)]
-tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("MUSICA_REDUCE_D", "MUSICA_REDUCE_AUX", "MUSICA_COPY_MODE", "MUSICA_COPY_BLOCKS") if k in os.environ)
+tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("MUSICA_REDUCE_ROWS",) if k in os.environ)
 p = mp.MusicaProcessing()
 assert p.init(64, levels=4)
 for side, nbuf in cases:

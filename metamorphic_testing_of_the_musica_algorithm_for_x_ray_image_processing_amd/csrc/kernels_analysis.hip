@@ -182,61 +182,16 @@ __global__ void k_sqrt(const uint16_t* __restrict__ px, float* __restrict__ out,
 }
 
 // ---- K10 + K11: row pieces in sdev_parts.h ------------------------------------------------
-// rows_per_wave must be a multiple of 16 (histogram runs start at y % 16 == 0) and of T.
+// rows_per_wave must be a multiple of 16 (histogram runs start at y % 16 == 0).
 // cov = (imageSize / 512) * 512: the part of the grid the reference's dispatch covers (src/vk_processing.cpp:2293-2295).
-// T rows per loop trip: the T new rows are loaded back to back before any arithmetic.
-template <int T, bool HIST>
-__global__ __launch_bounds__(kBlockThreads) void k_sdev_hist(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
-                                                             size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov,
-                                                             int rows_per_wave) {
-    __shared__ uint32_t lh[MUSICA_NOISE_BINS + 64];  // + one scratch word per lane for the branch-free adds
-    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS + 64; i += blockDim.x) lh[i] = 0u;
-    __syncthreads();
-    const int img = blockIdx.z;
-    const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
-    sdev += (size_t)img * plane;
-    const int lane = threadIdx.x & 63;
-    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
-    const int y0 = seg * rows_per_wave;
-    const SCfg g = make_scfg(blockIdx.x, lane, S);
-    const uint32_t rb = (uint32_t)pitch * 4u;
-    auto roff = [&](int row) -> uint32_t { return (row >= 0 && row < S) ? (uint32_t)row * rb : kOob; };
-    if (y0 < S) {
-        const int y1 = min(y0 + rows_per_wave, S);
-        SRow w[T + 4];  // rows y-2 .. y+T+1
-        load_srow(w[0], bb, roff(y0 - 2), g, S);
-        load_srow(w[1], bb, roff(y0 - 1), g, S);
-        load_srow(w[2], bb, roff(y0), g, S);
-        load_srow(w[3], bb, roff(y0 + 1), g, S);
-        bool alive[8] = {false, false, false, false, false, false, false, false};
-        for (int y = y0; y < y1; y += T) {
-#pragma unroll
-            for (int t = 0; t < T; t++) load_srow(w[t + 4], bb, roff(y + t + 2), g, S);
-#pragma unroll
-            for (int t = 0; t < T; t++) {
-                if (y + t < y1)  // wave-uniform
-                    sdev_row<HIST>(w[t], w[t + 1], w[t + 2], w[t + 3], w[t + 4], g, S, y + t, cov, sdev + (size_t)(y + t) * pitch, lh, alive);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) w[i] = w[T + i];
-        }
-    }
-    __syncthreads();
-    uint32_t* gh = hist + (size_t)img * hist_stride;
-    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS; i += blockDim.x) {
-        const uint32_t v = lh[i];
-        if (v) atomicAdd(&gh[i], v);
-    }
-}
-
 // Software-pipelined form: one row per trip; the raw row of trip y+1 is requested before trip y is
 // computed and squared only when it enters the window (so the request never blocks the arithmetic).
 template <bool HIST>
 __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
                                                                 size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov,
                                                                 int rows_per_wave) {
-    __shared__ uint32_t lh[MUSICA_NOISE_BINS + 64];
-    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS + 64; i += blockDim.x) lh[i] = 0u;
+    __shared__ uint32_t lh[kHistLdsWords];
+    hist_lds_clear(lh);
     __syncthreads();
     const int img = blockIdx.z;
     const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
@@ -265,11 +220,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __r
         }
     }
     __syncthreads();
-    uint32_t* gh = hist + (size_t)img * hist_stride;
-    for (int i = threadIdx.x; i < MUSICA_NOISE_BINS; i += blockDim.x) {
-        const uint32_t v = lh[i];
-        if (v) atomicAdd(&gh[i], v);
-    }
+    hist_lds_flush(lh, hist + (size_t)img * hist_stride);
 }
 
 // histogram only (kernel-level parity tests feed a foreign sdev image): same scan, no stencil.
@@ -581,14 +532,8 @@ void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const Leve
                       int batch, int rows_per_wave) {
     const int strips = (l.S + kStripCols - 1) / kStripCols;
     const int segs = (l.S + rows_per_wave - 1) / rows_per_wave;
-    static const int dbg = getenv("MUSICA_DEBUG_SDEV") ? atoi(getenv("MUSICA_DEBUG_SDEV")) : 0;  // timing experiments only
     const dim3 grid(strips, (segs + kWavesPerBlock - 1) / kWavesPerBlock, batch);
-    if (dbg == 1) hipLaunchKernelGGL((k_sdev_hist<4, false>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
-    else if (dbg == 2) hipLaunchKernelGGL((k_sdev_hist<1, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
-    else if (dbg == 3) hipLaunchKernelGGL((k_sdev_hist<2, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
-    else if (dbg == 5) hipLaunchKernelGGL((k_sdev_hist_pf<false>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
-    else if (dbg == 4) hipLaunchKernelGGL((k_sdev_hist<4, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
-    else hipLaunchKernelGGL((k_sdev_hist_pf<true>), grid, dim3(kBlockThreads), l.S >= 2048 ? l0_lds_pad() : 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
+    hipLaunchKernelGGL((k_sdev_hist_pf<true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
 }
 
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch) {

@@ -5,7 +5,8 @@
 //              no halo rows, no halo columns, three adds per loaded float4. bench.py times it beside
 //              k_reduce_fast_pf, the same rotating-buffer way, so that the metric kernel's fraction of the
 //              8 TB/s HBM peak can also be read against what a streaming kernel of this shape attains on
-//              the same box (musica_k_copy41_timed_rot, include/musica.h).
+//              the same box (musica_k_copy41_timed_rot, include/musica.h). A grid-stride form (2048 / 4096 workgroups streaming
+//              4 contiguous 16-byte loads per trip) measured the same 16.0 us at 4096^2 from HBM, non-temporal loads 22 us.
 #include <stdlib.h>
 #include "kernels_common.h"
 #include "launchers.h"
@@ -26,30 +27,8 @@ __global__ __launch_bounds__(256) void k_copy41(const float4* __restrict__ in, f
     out[(size_t)yo * So4 + xo] = o;
 }
 
-// Variants for finding the attainable ceiling (MUSICA_COPY_MODE): 1 = grid-stride over 2048 workgroups, every thread streams
-// 4 contiguous 16-byte loads + 1 store per trip; 2 = the same with non-temporal loads.
-template <int AUX>
-__global__ __launch_bounds__(256) void k_copy41_flat(const float* __restrict__ in, float* __restrict__ out, size_t nout4, size_t in_bytes, size_t out_bytes) {
-    const Buf ib = make_buf(in, in_bytes), ob = make_buf(out, out_bytes);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nout4; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t o = (uint32_t)(i * 64);
-        const float4 a = bload4_aux<AUX>(ib, o), b = bload4_aux<AUX>(ib, o + 16u), c = bload4_aux<AUX>(ib, o + 32u), d = bload4_aux<AUX>(ib, o + 48u);
-        float4 r;
-        r.x = a.x + b.x + c.x + d.x; r.y = a.y + b.y + c.y + d.y; r.z = a.z + b.z + c.z + d.z; r.w = a.w + b.w + c.w + d.w;
-        bstore4(ob, (uint32_t)(i * 16), r);
-    }
-}
-
 void launch_copy41(hipStream_t st, const float* in, float* out, int side) {
     const int So = side / 2, So4 = So / 4;
-    static const int mode = getenv("MUSICA_COPY_MODE") ? atoi(getenv("MUSICA_COPY_MODE")) : 0;
-    if (mode) {
-        const size_t nout4 = (size_t)So * So4, inb = (size_t)side * side * 4, outb = (size_t)So * So * 4;
-        static const int blocks = getenv("MUSICA_COPY_BLOCKS") ? atoi(getenv("MUSICA_COPY_BLOCKS")) : 2048;
-        if (mode == 2) hipLaunchKernelGGL(k_copy41_flat<2>, dim3(blocks), dim3(256), 0, st, in, out, nout4, inb, outb);
-        else hipLaunchKernelGGL(k_copy41_flat<0>, dim3(blocks), dim3(256), 0, st, in, out, nout4, inb, outb);
-        return;
-    }
     hipLaunchKernelGGL(k_copy41, dim3((So4 + 255) / 256, So), dim3(256), 0, st, reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out),
                        side / 4, So4);
 }

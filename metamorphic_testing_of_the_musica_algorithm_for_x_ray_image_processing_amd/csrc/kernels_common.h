@@ -56,12 +56,6 @@ __device__ __forceinline__ float4 bload4(const Buf& b, uint32_t off) {
     const v4f v = llvm_buffer_load_v4f32(b.r, (int)off, 0, 0);
     return make_float4(v.x, v.y, v.z, v.w);
 }
-// The same with a cache-policy immediate (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).
-template <int AUX>
-__device__ __forceinline__ float4 bload4_aux(const Buf& b, uint32_t off) {
-    const v4f v = llvm_buffer_load_v4f32(b.r, (int)off, 0, AUX);
-    return make_float4(v.x, v.y, v.z, v.w);
-}
 __device__ __forceinline__ float2 bload2(const Buf& b, uint32_t off) {
     const v2f v = llvm_buffer_load_v2f32(b.r, (int)off, 0, 0);
     return make_float2(v.x, v.y);

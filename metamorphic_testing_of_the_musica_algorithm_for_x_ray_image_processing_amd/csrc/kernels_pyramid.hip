@@ -71,9 +71,8 @@ struct RowR {
     float hr;        // column c0+512 of the strip (lane 63 only)
 };
 
-template <int AUX = 0>
 __device__ __forceinline__ void load8(float d[8], const Buf& b, uint32_t off) {
-    const float4 a = bload4_aux<AUX>(b, off), c = bload4_aux<AUX>(b, off + 16u);
+    const float4 a = bload4(b, off), c = bload4(b, off + 16u);
     d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = c.x; d[5] = c.y; d[6] = c.z; d[7] = c.w;
 }
 __device__ __forceinline__ void store8(const Buf& b, uint32_t off, const float d[8]) {
@@ -81,9 +80,8 @@ __device__ __forceinline__ void store8(const Buf& b, uint32_t off, const float d
     bstore4(b, off + 16u, make_float4(d[4], d[5], d[6], d[7]));
 }
 
-template <int AUX = 0>
 __device__ __forceinline__ void load_row(RowR& r, const Buf& b, uint32_t row_off, const LaneCfg& g) {
-    load8<AUX>(r.v, b, g.off + row_off);
+    load8(r.v, b, g.off + row_off);
     const float2 h = bload2(b, g.off_l + row_off);
     r.hl0 = h.x; r.hl1 = h.y;
     r.hr = bload1(b, g.off_r + row_off);
@@ -124,7 +122,7 @@ __device__ __forceinline__ void reduce_row(const RowR& r0, const RowR& r1, const
 // TAG only separates the launch sites in profiler output (one symbol per site, so rocprofv3's
 // per-kernel averages are not a mix of pyramid levels): 0 = level 0 of the pipeline, 1 = levels >= 1,
 // 2 = stand-alone musica_k_reduce, 3 = init-time autotune, 4 = stand-alone rotating over distinct planes (musica_k_reduce_timed_rot).
-template <int D, int TAG, int AUX = 0>
+template <int D, int TAG>
 __global__ __launch_bounds__(kBlockThreads) void k_reduce_fast_pf(const float* __restrict__ in, float* __restrict__ out,
                                                                   int S, int pitch, size_t in_plane, int So, int opitch,
                                                                   size_t out_plane, int rows_per_wave) {
@@ -146,20 +144,20 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_fast_pf(const float* _
     const int n = yo1 - yo0;
     const int yfirst = dir > 0 ? yo0 : yo1 - 1;
     RowR w[5 + 2 * D];
-    load_row<AUX>(w[0], ib, (uint32_t)mirror_idx(2 * yfirst - 2 * dir, hi) * rb, g);
-    load_row<AUX>(w[1], ib, (uint32_t)mirror_idx(2 * yfirst - dir, hi) * rb, g);
-    load_row<AUX>(w[2], ib, (uint32_t)(2 * yfirst) * rb, g);
+    load_row(w[0], ib, (uint32_t)mirror_idx(2 * yfirst - 2 * dir, hi) * rb, g);
+    load_row(w[1], ib, (uint32_t)mirror_idx(2 * yfirst - dir, hi) * rb, g);
+    load_row(w[2], ib, (uint32_t)(2 * yfirst) * rb, g);
 #pragma unroll
     for (int d = 0; d < D; d++) {  // trips 0 .. D-1 (clamped: rows past the segment are requested, never consumed)
         const int ya = yfirst + dir * min(d, n - 1);
-        load_row<AUX>(w[3 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + dir, hi) * rb, g);
-        load_row<AUX>(w[4 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + 2 * dir, hi) * rb, g);
+        load_row(w[3 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + dir, hi) * rb, g);
+        load_row(w[4 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + 2 * dir, hi) * rb, g);
     }
     for (int t = 0; t < n; t++) {
         const int yo = yfirst + dir * t;
         const int yn = yfirst + dir * min(t + D, n - 1);
-        load_row<AUX>(w[3 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + dir, hi) * rb, g);
-        load_row<AUX>(w[4 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + 2 * dir, hi) * rb, g);
+        load_row(w[3 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + dir, hi) * rb, g);
+        load_row(w[4 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + 2 * dir, hi) * rb, g);
         if (dir > 0) reduce_row(w[0], w[1], w[2], w[3], w[4], g, ob, (uint32_t)yo * orb);  // wave-uniform
         else reduce_row(w[4], w[3], w[2], w[1], w[0], g, ob, (uint32_t)yo * orb);
 #pragma unroll
@@ -754,12 +752,6 @@ void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* 
     if (fast_ok(li.S) && !force_generic) {
         const dim3 grid = stream_grid(li.S, lo.S, rows_per_wave, batch);
         auto* kern = tag == 0 ? k_reduce_fast_pf<1, 0> : tag == 1 ? k_reduce_fast_pf<1, 1> : tag == 2 ? k_reduce_fast_pf<1, 2> : tag == 3 ? k_reduce_fast_pf<1, 3> : k_reduce_fast_pf<1, 4>;
-        if (tag == 4) {   // experiments on the stand-alone rotating launch: prefetch depth and cache policy of the streaming loads
-            static const int d = getenv("MUSICA_REDUCE_D") ? atoi(getenv("MUSICA_REDUCE_D")) : 1;
-            static const int aux = getenv("MUSICA_REDUCE_AUX") ? atoi(getenv("MUSICA_REDUCE_AUX")) : 0;
-            if (d == 2) kern = aux == 2 ? k_reduce_fast_pf<2, 4, 2> : k_reduce_fast_pf<2, 4, 0>;
-            else if (aux == 2) kern = k_reduce_fast_pf<1, 4, 2>;
-        }
         hipLaunchKernelGGL(kern, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
     } else {
         hipLaunchKernelGGL(k_reduce_generic, generic_grid(lo.S, batch), kGenericBlock, 0, st, in, out, li.S, li.pitch,
@@ -778,9 +770,9 @@ void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, fl
     const dim3 grid = stream_grid(lf.S, lc.S, rows_per_wave, batch);
     const float* fine = reinterpret_cast<const float*>(px);
     if (rows_per_trip >= 2)
-        hipLaunchKernelGGL((k_band_fast<2, true>), grid, dim3(kBlockThreads), l0_lds_pad(), st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
+        hipLaunchKernelGGL((k_band_fast<2, true>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
     else
-        hipLaunchKernelGGL((k_band_fast<1, true>), grid, dim3(kBlockThreads), l0_lds_pad(), st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
+        hipLaunchKernelGGL((k_band_fast<1, true>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
 }
 
 void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc,

@@ -56,8 +56,6 @@ struct GradArgs {
     const uint32_t* only_if; // non-NULL: images whose word is 0 are skipped (fix-up launch behind the fused expand kernel)
 };
 
-// experiment: dynamic LDS bytes added to the level-0 band / sdev launches (caps their workgroups per CU, leaving wave slots free)
-static inline unsigned l0_lds_pad() { static const int v = getenv("MUSICA_L0_LDS_PAD") ? atoi(getenv("MUSICA_L0_LDS_PAD")) : 0; return (unsigned)v; }
 // kernels_pyramid.hip
 void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave, bool force_generic, int tag);
 void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave, bool force_generic, int rows_per_trip);
