@@ -534,10 +534,13 @@ template <int GAIN, bool NR, int T, bool GH, int W = 1>
 __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) {
     __shared__ CurveLds tab;
     __shared__ __attribute__((aligned(16))) LutLds lut;
-    __shared__ uint32_t lh[GH ? MUSICA_GRAD_BINS + 64 : 1];  // + one scratch word per lane for the branch-free adds
+    // four bank-staggered copies of the histogram (lane l adds into copy l % 4, see sdev_parts.h: neighbouring texels share bins,
+    // and lanes of one ds_add that hit the same address are served one after the other); word 1024 of a copy takes what is out of range
+    constexpr int kGhCopies = 4, kGhStride = MUSICA_GRAD_BINS + 8;
+    __shared__ uint32_t lh[GH ? kGhCopies * kGhStride : 1];
     const int img = blockIdx.z;
     if (GH)
-        for (int i = threadIdx.x; i < MUSICA_GRAD_BINS + 64; i += blockDim.x) lh[i] = 0u;
+        for (int i = threadIdx.x; i < kGhCopies * kGhStride; i += blockDim.x) lh[i] = 0u;
     if (GAIN == GAIN_CURVE) {
         const DevCurve* cv = a.curves + (size_t)img * a.curve_stride;
         const DevCurveLut* lv = a.luts + (size_t)img * MUSICA_COARSER_LEVELS_START;
@@ -577,6 +580,7 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
             if (g.active && (uint32_t)(g.c + j) > border && (uint32_t)(g.c + j) < lim) colin |= 1u << j;
     }
     const int thr = GH ? a.thr090[img] : 0;
+    uint32_t* lhc = lh + (GH ? (lane & (kGhCopies - 1)) * kGhStride : 0);
 
     CRow cw[T + 2];
     load_crow(cw[0], pb, (uint32_t)coarse_of_fine(2 * k0 - 2, S) * crb, g);
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
                             const uint32_t bin = min((uint32_t)(int)fminf(fmaxf(cur * (float)MUSICA_GRAD_BINS, -1.0f), 2048.0f), (uint32_t)MUSICA_GRAD_BINS);
                             // :28-30 uint(relevant * 100): 0 outside the border; adding 0 leaves the histogram as it is
                             const uint32_t w = ((m >> j) & 1u) * (px <= thr ? w_dark_or_ramp : w_cnr);
-                            atomicAdd(&lh[bin], w);
+                            atomicAdd(&lhc[bin], w);
                         }
                     }
                 }
@@ -673,7 +677,9 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
         __syncthreads();
         uint32_t* gh = a.ghist + (size_t)img * MUSICA_GRAD_BINS;
         for (int i = threadIdx.x; i < MUSICA_GRAD_BINS; i += blockDim.x) {
-            const uint32_t v = lh[i];
+            uint32_t v = 0u;
+#pragma unroll
+            for (int k = 0; k < kGhCopies; k++) v += lh[k * kGhStride + i];
             if (v) atomicAdd(&gh[i], v);
         }
     }

@@ -65,11 +65,8 @@ struct musica_ctx {
     hipStream_t cur;         // stream the run_*_level helpers launch on (stream or side)
     hipStream_t side;        // coarse-level chain runs here, concurrently with the level-0 kernels on `stream`
     hipEvent_t ev_fork, ev_join;
-    hipStream_t side1;       // dag == 3: level 1 (band, sdev, then curves + expand 2, 1) beside level 0 on `stream` and levels >= 2 on `side`
+    hipStream_t side1;       // dag == 1: sdev 2 beside the coarse chain
     hipEvent_t ev_s1, ev_s2;
-    // per-level dispatch (dag == 2): band + sdev of level i run on lvs[i] as soon as reduce i is done
-    hipStream_t lvs[MUSICA_MAX_LEVELS];
-    hipEvent_t ev_r[MUSICA_MAX_LEVELS], ev_l[MUSICA_MAX_LEVELS];
     bool fuse_u16;           // level-0 kernels read the raw uint16 pixels; the normalized image is produced on demand only
     bool norm_valid;         // d_norm holds the normalized image of the current input
     // hipGraph replay of the two-stream dispatch (captured once per input pointer; MUSICA_FLAG_NO_GRAPH /
@@ -78,8 +75,7 @@ struct musica_ctx {
     hipGraphExec_t graph_exec[2];      // one captured graph per input pointer, the two most recently used (the streaming
     const uint16_t* graph_input[2];    // path alternates between two device input buffers)
     int graph_next;                    // slot the next capture overwrites
-    int dag;                 // 0: one in-order stream; 1: two streams (levels 0-1 | coarse chain); 2: one stream per level;
-                             // 3: three streams (level 0 | level 1 + curve-dependent expands | levels >= 2)
+    int dag;                 // 0: one in-order stream; 1: three streams (levels 0-1 | coarse chain | sdev 2)
     // device state
     uint16_t* d_input;
     uint16_t* d_input2;      // second input buffer of the streaming path (musica_execute_stream), allocated on first use
@@ -209,26 +205,6 @@ static int pick_groups(const musica_ctx* c) {
     return g < 1 ? 1 : g;
 }
 
-static bool create_level_streams(musica_ctx* c) {
-    bool ok = true;
-    for (int i = 0; i < MUSICA_MAX_LEVELS; i++) { c->lvs[i] = nullptr; c->ev_r[i] = nullptr; c->ev_l[i] = nullptr; }
-    if (c->dag != 2) return true;
-    for (int i = 0; i < c->L && ok; i++) {
-        ok = ok && hipStreamCreateWithFlags(&c->lvs[i], hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&c->ev_l[i], hipEventDisableTiming) == hipSuccess;
-    }
-    return ok;
-}
-static void destroy_level_streams(musica_ctx* c) {
-    for (int i = 0; i < MUSICA_MAX_LEVELS; i++) {
-        if (c->lvs[i]) { hipStreamSynchronize(c->lvs[i]); hipStreamDestroy(c->lvs[i]); }
-        if (c->ev_r[i]) hipEventDestroy(c->ev_r[i]);
-        if (c->ev_l[i]) hipEventDestroy(c->ev_l[i]);
-        c->lvs[i] = nullptr; c->ev_r[i] = nullptr; c->ev_l[i] = nullptr;
-    }
-}
-
 static void copy_rows(musica_ctx* dst, const musica_ctx* src) {
     if (dst == src) return;
     memcpy(dst->rows_reduce, src->rows_reduce, sizeof(src->rows_reduce));
@@ -303,7 +279,6 @@ static bool make_views(musica_ctx* c, int groups) {
         ok = ok && hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&v->ev_gdone, hipEventDisableTiming) == hipSuccess;
-        ok = ok && create_level_streams(v);
         v->cur = v->stream;
     }
     return ok;
@@ -334,7 +309,6 @@ void musica_destroy(musica_ctx* c) {
         if (v->ev_fork) hipEventDestroy(v->ev_fork);
         if (v->ev_join) hipEventDestroy(v->ev_join);
         if (v->ev_gdone) hipEventDestroy(v->ev_gdone);
-        destroy_level_streams(v);
         for (int k = 0; k < 2; k++) if (v->graph_exec[k]) hipGraphExecDestroy(v->graph_exec[k]);
         delete v;
     }
@@ -347,7 +321,6 @@ void musica_destroy(musica_ctx* c) {
     for (auto& s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (void* p : c->allocations) hipFree(p);
     for (int k = 0; k < 2; k++) if (c->graph_exec[k]) hipGraphExecDestroy(c->graph_exec[k]);
-    destroy_level_streams(c);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c->side1) { hipStreamSynchronize(c->side1); hipStreamDestroy(c->side1); }
     if (c->ev_s1) hipEventDestroy(c->ev_s1);
@@ -433,13 +406,11 @@ static musica_ctx* create_impl(const musica_params* params) {
     ok = ok && hipStreamCreateWithFlags(&c->side1, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_s1, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_s2, hipEventDisableTiming) == hipSuccess;
-    // little work per step (<= 8 Mpixel): the per-level form wins (one 2048^2 image: 0.229 vs 0.241 ms, shorter dependent
-    // chain); more: the two-stream form (8 x 2048^2: 0.564 vs 0.571 ms; one 8192^2: 1.05 vs 1.11 ms — the reduce chain
-    // of the per-level form crawls among the big kernels, and running the whole reduce chain first costs 0.69 ms)
-    c->dag = env_int("MUSICA_DAG", (size_t)c->B * N * N <= ((size_t)8 << 20) ? 2 : 1);
-    if (c->dag < 0 || c->dag > 3) c->dag = 1;
-    for (int i = 0; i < MUSICA_MAX_LEVELS; i++) { c->lvs[i] = nullptr; c->ev_r[i] = nullptr; c->ev_l[i] = nullptr; }
-    ok = ok && create_level_streams(c);
+    // 1: the three-stream form (enqueue_dag); 0: one in-order stream, the reference's order. (A one-stream-per-level form was the
+    // default for single images in round 1; the three-stream form with its present ordering is faster for every workload
+    // measured: one 2048^2 image 0.204 vs 0.215 ms, 4096^2 + CLAHE 0.609 vs 0.633 ms.)
+    c->dag = env_int("MUSICA_DAG", 1);
+    if (c->dag < 0 || c->dag > 1) c->dag = 1;
     c->use_graph = c->dag && !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", 1) != 0;
     c->graph_exec[0] = c->graph_exec[1] = nullptr;
     c->graph_input[0] = c->graph_input[1] = nullptr;
@@ -707,11 +678,29 @@ static void enqueue_gradation(musica_ctx* c, bool fused) {
     { Span sp(c, MUSICA_KERNEL_GRAD_APPLY); launch_grad_apply(c->stream, c->d_recon[0], c->d_graded, l0, c->d_gcurve, c->B); }
 }
 
-// Two-stream form of the dispatch script. The reference submits everything to one in-order queue;
-// the data dependences allow more: once level 0 is smoothed (R0), the whole coarse chain
-// R1 B1 S1 R2 B2 S2 ... (small, launch- and latency-bound kernels) is independent of the two big
-// level-0 kernels B0 and S0, so it runs on a second stream underneath them and rejoins before the
-// curves are generated. Same kernels, same arguments, same results.
+// Three-stream form of the dispatch script (dag == 1, the default for batches and large images). The reference submits
+// everything to one in-order queue; the data dependences allow more:
+//   stream : clear minmax R0 R1 | B0 S0 B1 S1 (wait side, side1) E3 curves E2 E1 E0 gradation
+//   side   :                    | R2 .. R(L-1) B2 B3 . B4 .. E(L-1) .. E4 S3
+//   side1  :                                    (B2) S2
+// Small kernels only get wave slots in the tails of a chip-filling kernel beside them (rocprofv3 timeline: a 6 us reduce waits
+// 30 us behind band 0; sdev 2 and sdev 3 sit out sdev 0, whose 4096 wavefronts hold every slot for the whole launch), so the
+// order on the side streams is chosen to have as little as possible left when sdev 0 ends: first everything that reads neither a
+// histogram nor an sdev image — the reduce chain, the band-pass images, the constant-gain expand slots above level 3 — then
+// sdev 3 behind them and sdev 2 on a third stream as soon as band 2 exists (20 us kernels: a wavefront walks a 16-row run row
+// by row); they end up under band 1 / sdev 1 instead of in front of the curves (-10 us per step against sdev 2 / sdev 3 in
+// the side chain, where ~100 us of small launches still followed them). Same kernels, same arguments, same results.
+// Issue order = capture order: a graph replay enqueues its nodes in capture order, a few microseconds each, so the main
+// stream's kernels are captured before the side chains (with the side chains first, band 0 started 45 us late).
+// Measured and not kept (same box, A/B): level 1 ahead of level 0 on the main stream with the curves of levels >= 1 and
+// expand 3 / 2 / 1 on a side stream beside the level-0 kernels (0.528 - 0.538 ms against 0.518 - 0.527: the side work still
+// only runs once sdev 0 drains, and hipGraph maps the extra branches onto fewer queues than captured); a high-priority side
+// stream (no effect); CU-masked streams (32 / 224 CU split: 5 % slower); dynamic-LDS padding of the level-0 launches to keep
+// a workgroup slot per CU free (no effect on the waiting kernels); one launch for band 0 + band 1 and one for sdev 0 + sdev 1
+// (-11 us of kernel time but no change of the step: the side chain was the critical path); the first one, two or all reduce
+// launches of the side chain on the main stream ahead of the fork (within +-1 %); one 1024-thread workgroup per
+// image for the whole tail of levels >= 3 (bit-exact, but 153 us for one image — a single CU walks it row by row — against
+// ~100 us for the ten launches it replaces).
 static void enqueue_dag(musica_ctx* c) {
     const int L = c->L;
     c->cur = c->stream;
@@ -721,155 +710,44 @@ static void enqueue_dag(musica_ctx* c) {
     { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, 1, c->rows_reduce[1]); }
     hipEventRecord(c->ev_fork, c->stream);
     hipStreamWaitEvent(c->side, c->ev_fork, 0);
-    // main stream first: the bandwidth-bound kernels of levels 0 and 1. Issue order matters — a graph replay enqueues
-    // its nodes in capture order at ~3.5 us each, so whatever is issued last starts tens of microseconds late
-    // (rocprofv3 timeline: with the side chain first, level-0 band started 45 us after its input was ready).
-    // Measured and not kept: a high-priority side stream (no effect: the long-lived wavefronts of the streaming
-    // kernels hold the wave slots either way) and CU-masked streams (32 / 224 CU split: 5 % slower).
     c->cur = c->stream;
     for (int i = 0; i < 2; i++) {
         { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
         { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
     }
-    // side stream: everything of levels >= 2 that does not need a histogram-derived curve —
-    // reduce / band / sdev of levels 2.., then the expand slots of levels L-1 .. 3 (constant gain above
-    // level 3, range gain at level 3: neither reads a curve, src/vk_processing.cpp:259-293)
     c->cur = c->side;
-    for (int i = 2; i < L; i++) {
-        { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
-        { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
-        if (i <= MUSICA_CNR_LEVEL) { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
-    }
-    for (int lvl = L - 1; lvl >= MUSICA_CNR_LEVEL; lvl--) {
+    for (int i = 2; i < L; i++) { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
+    for (int i = 2; i <= MUSICA_CNR_LEVEL; i++) { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
+    hipEventRecord(c->ev_s2, c->side);   // band 2 (and 3) exist
+    hipStreamWaitEvent(c->side1, c->ev_s2, 0);
+    c->cur = c->side1;
+    { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, 2, c->rows_sdev[2]); }
+    hipEventRecord(c->ev_s1, c->side1);
+    c->cur = c->side;
+    for (int i = MUSICA_CNR_LEVEL + 1; i < L; i++) { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
+    for (int lvl = L - 1; lvl > MUSICA_CNR_LEVEL; lvl--) {
         Span sp(c, MUSICA_KERNEL_EXPAND_REST);
         run_expand_level(c, lvl, c->rows_expand[lvl]);
     }
+    { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, MUSICA_CNR_LEVEL, c->rows_sdev[MUSICA_CNR_LEVEL]); }
     hipEventRecord(c->ev_join, c->side);
     c->cur = c->stream;
-    hipStreamWaitEvent(c->stream, c->ev_join, 0);
-    {   // curves of every level + cnr of level 3 in one launch (kernels_analysis.hip k_curves_cnr)
-        Span sp(c, MUSICA_KERNEL_CURVES);
-        launch_curves_cnr(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
-                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_thr090);
-    }
-    for (int lvl = MUSICA_CNR_LEVEL - 1; lvl >= 0; lvl--) {
-        Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
-        run_expand_level(c, lvl, c->rows_expand[lvl]);
-    }
-    enqueue_gradation(c, true);
-}
-
-// Per-level form of the dispatch script (dag == 2): the only true dependences are
-//   reduce i -> reduce i+1;  reduce i -> band i -> sdev i;  band i (+ sdev 3) and expand i+1 -> expand i for i >= 3;
-//   every sdev -> curves -> cnr -> expand 2 -> 1 -> 0 -> gradation.
-// So the reduce chain runs straight down on the main stream, each level's band + sdev start on their own stream
-// the moment their reduce is done (level 0's band no longer waits for reduce 1), and the curve-free expand slots
-// follow the reduce chain. The critical path of the middle of the step becomes band 0 -> sdev 0 instead of the
-// sum of a 13-kernel chain slowed down by the big kernels it shares the chip with.
-static void enqueue_dag_levels(musica_ctx* c) {
-    const int L = c->L;
-    c->cur = c->stream;
-    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B, c->d_grad_hist_b, c->d_gzero);  // :2153-2162
-    enqueue_norm(c);
-    for (int i = 0; i < L; i++) {
-        c->cur = c->stream;
-        { Span sp(c, i == 0 ? MUSICA_KERNEL_REDUCE_L0 : MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
-        hipEventRecord(c->ev_r[i], c->stream);
-        hipStreamWaitEvent(c->lvs[i], c->ev_r[i], 0);
-        c->cur = c->lvs[i];
-        { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
-        if (i <= MUSICA_CNR_LEVEL) { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
-        hipEventRecord(c->ev_l[i], c->lvs[i]);
-    }
-    // the curve-free expand slots L-1 .. 3 follow the reduce chain on the main stream (idle until the curves anyway);
-    // every cross-stream wait is "capture-origin stream waits for a forked stream", the one join shape that the
-    // ROCm 7.0 runtime's hipStreamEndCapture handles (see enqueue_groups)
-    c->cur = c->stream;
-    for (int lvl = L - 1; lvl >= MUSICA_CNR_LEVEL; lvl--) {
-        hipStreamWaitEvent(c->stream, c->ev_l[lvl], 0);
-        Span sp(c, MUSICA_KERNEL_EXPAND_REST);
-        run_expand_level(c, lvl, c->rows_expand[lvl]);
-    }
-    for (int i = 0; i < MUSICA_CNR_LEVEL; i++) hipStreamWaitEvent(c->stream, c->ev_l[i], 0);
-    {   // curves of every level + cnr of level 3 in one launch (kernels_analysis.hip k_curves_cnr)
-        Span sp(c, MUSICA_KERNEL_CURVES);
-        launch_curves_cnr(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
-                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_thr090);
-    }
-    for (int lvl = MUSICA_CNR_LEVEL - 1; lvl >= 0; lvl--) {
-        Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
-        run_expand_level(c, lvl, c->rows_expand[lvl]);
-    }
-    enqueue_gradation(c, true);
-}
-
-// Three-stream form (dag == 3). What starts the biggest kernel of the tail — expand of level 0, then the gradation stage — is
-// (a) the level-0 curve, i.e. sdev 0, and (b) the reconstruction of level 1. In the two-stream form (b) only starts after sdev 0
-// (band 1, sdev 1, curves, expand 2, expand 1: ~140 us of kernels that each fill a fraction of the chip). Here level 1 has a stream
-// of its own next to level 0, the curves of levels >= 1 (+ cnr) are generated as soon as their histograms exist, and level 0
-// gets a one-workgroup-per-image curve launch of its own behind sdev 0:
-//   stream : clear minmax R0 R1 | B0 S0 curve0 ......................... (wait side1) E0 gradation
-//   side1  :                    | B1 S1 (wait side) curves1..L-1+cnr E2 E1
-//   side   :                    | R2 B2 S2 R3 B3 S3 R4 B4 ... E(L-1) .. E3
-// Capture order = issue order (a replay enqueues its nodes in capture order, a few microseconds each): level 0 first — band 0 is
-// the long pole and the dozen small launches of the side chains are enqueued while it runs.
-static void enqueue_dag3(musica_ctx* c) {
-    const int L = c->L;
-    c->cur = c->stream;
-    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B, c->d_grad_hist_b, c->d_gzero);  // :2153-2162
-    enqueue_norm(c);
-    { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_level(c, 0, c->rows_reduce[0]); }
-    { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, 1, c->rows_reduce[1]); }
-    hipEventRecord(c->ev_fork, c->stream);
-    hipStreamWaitEvent(c->side, c->ev_fork, 0);
-    hipStreamWaitEvent(c->side1, c->ev_fork, 0);
-    // level 0
-    c->cur = c->stream;
-    { Span sp(c, MUSICA_KERNEL_BAND_L0); run_band_level(c, 0, c->rows_band[0]); }
-    { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, 0, c->rows_sdev[0]); }
-    {
-        Span sp(c, MUSICA_KERNEL_CURVES);
-        launch_noise_curves(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
-                            c->d_minmax, c->min_chain_exact, nullptr, 0, 1);
-    }
-    // levels >= 2: nothing here needs a histogram-derived curve (constant gain above level 3, range gain at level 3)
-    c->cur = c->side;
-    for (int i = 2; i < L; i++) {
-        { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
-        { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
-        if (i <= MUSICA_CNR_LEVEL) { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
-    }
-    for (int lvl = L - 1; lvl >= MUSICA_CNR_LEVEL; lvl--) {
-        Span sp(c, MUSICA_KERNEL_EXPAND_REST);
-        run_expand_level(c, lvl, c->rows_expand[lvl]);
-    }
-    hipEventRecord(c->ev_s2, c->side);
-    // level 1, then everything of levels 2 and 1 that needs a curve
-    c->cur = c->side1;
-    { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, 1, c->rows_band[1]); }
-    { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, 1, c->rows_sdev[1]); }
-    hipStreamWaitEvent(c->side1, c->ev_s2, 0);
-    {
-        Span sp(c, MUSICA_KERNEL_CURVES);
-        launch_curves_cnr(c->side1, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
-                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_thr090, 1);
-    }
-    for (int lvl = MUSICA_CNR_LEVEL - 1; lvl >= 1; lvl--) {
-        Span sp(c, MUSICA_KERNEL_EXPAND_REST);
-        run_expand_level(c, lvl, c->rows_expand[lvl]);
-    }
-    hipEventRecord(c->ev_s1, c->side1);
-    c->cur = c->stream;
     hipStreamWaitEvent(c->stream, c->ev_s1, 0);
-    { Span sp(c, MUSICA_KERNEL_EXPAND_L0); run_expand_level(c, 0, c->rows_expand[0]); }
+    hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    { Span sp(c, MUSICA_KERNEL_EXPAND_REST); run_expand_level(c, MUSICA_CNR_LEVEL, c->rows_expand[MUSICA_CNR_LEVEL]); }
+    {   // curves of every level + cnr of level 3 in one launch (kernels_analysis.hip k_curves_cnr)
+        Span sp(c, MUSICA_KERNEL_CURVES);
+        launch_curves_cnr(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
+                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_thr090);
+    }
+    for (int lvl = MUSICA_CNR_LEVEL - 1; lvl >= 0; lvl--) {
+        Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
+        run_expand_level(c, lvl, c->rows_expand[lvl]);
+    }
     enqueue_gradation(c, true);
 }
 
-static void enqueue_dag_any(musica_ctx* c) {
-    if (c->dag == 3) enqueue_dag3(c);
-    else if (c->dag == 2) enqueue_dag_levels(c);
-    else enqueue_dag(c);
-}
+static void enqueue_dag_any(musica_ctx* c) { enqueue_dag(c); }
 
 // Captures enqueue_dag() (both streams: the side stream joins the capture through ev_fork and rejoins
 // through ev_join) into an executable graph for the current input pointer.

@@ -18,10 +18,11 @@ namespace musica {
 // Bins are privatised in LDS and flushed with one global atomic per non-empty bin. The noise values of an image crowd into a
 // few bins (phantoms: the fullest bin takes 5 % of the texels at level 0, 17 % at level 1, 25-28 % at levels 2-3), and lanes
 // of one ds_add that hit the same address are served one after the other — so the block keeps kHistCopies copies of the
-// histogram, lane l adds into copy l % kHistCopies (copies kHistCopyStride words apart: same bin, four different banks), and
-// the flush sums them.
-constexpr int kHistCopies = 4;
-constexpr int kHistCopyStride = MUSICA_NOISE_BINS + 8;                       // % 32 == 8: bin b of the four copies sits in banks b, b+8, b+16, b+24
+// histogram, lane l adds into copy l % kHistCopies (copies kHistCopyStride words apart: same bin, different banks), and the
+// flush sums them. Three copies = 24.9 KB per workgroup: six workgroups fit a CU's 160 KB, so the small sdev launches of
+// levels 2 and 3 find room beside the four-per-CU workgroups of level 0 (with four copies, 33 KB, they waited it out).
+constexpr int kHistCopies = 3;
+constexpr int kHistCopyStride = MUSICA_NOISE_BINS + 8;                       // % 32 == 8: bin b of the copies sits in banks b, b+8, b+16
 constexpr int kHistLdsWords = kHistCopies * kHistCopyStride + 64;           // + one scratch word per lane for the branch-free adds
 __device__ __forceinline__ void hist_lds_clear(uint32_t* lh) {
     for (int i = threadIdx.x; i < kHistLdsWords; i += blockDim.x) lh[i] = 0u;
@@ -144,7 +145,7 @@ __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const S
     // outside the image / the dispatch coverage start every run dead (their texel would read 0 -> break).
     if (HIST && y < cov) {
         const int lane = threadIdx.x & 63;
-        const int copy = (lane & (kHistCopies - 1)) * kHistCopyStride, scratch = kHistCopies * kHistCopyStride + lane;
+        const int copy = (lane % kHistCopies) * kHistCopyStride, scratch = kHistCopies * kHistCopyStride + lane;
         const bool rearm = (y & (kHistArea - 1)) == 0;   // wave-uniform
 #pragma unroll
         for (int j = 0; j < 8; j++) {

@@ -169,12 +169,12 @@ def test_image_groups_give_the_same_bits(ob, flags, monkeypatch):
 
 @pytest.mark.parametrize("batch", [1, 3])
 def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
-    """MUSICA_DAG = 0 (one in-order stream, the reference's order), 1 (two streams), 2 (one stream per level),
-    graph replay and eager: every form against the oracle, twice in a row (histograms re-cleared, events re-armed)."""
+    """MUSICA_DAG = 0 (one in-order stream, the reference's order) and 1 (three streams), graph replay and eager:
+    every form against the oracle, twice in a row (histograms re-cleared, events re-armed)."""
     n, levels = 1032, 6
     px = np.stack([phantom(n, 800 + k) for k in range(batch)])
     want = [ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[k]) for k in range(batch)]
-    for dag in ("0", "1", "2", "3"):
+    for dag in ("0", "1"):
         for flags in (0, mp.FLAG_NO_GRAPH):
             monkeypatch.setenv("MUSICA_DAG", dag)
             p = _proc(n, levels, batch=batch, flags=flags)
@@ -204,7 +204,7 @@ def test_kernel_variants_and_launch_geometries_give_the_same_bits(ob, env, monke
     p.cleanup()
 
 
-@pytest.mark.parametrize("dag", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("dag", ["0", "1"])
 def test_exact_zeros_in_the_reconstruction_take_the_literal_histogram(ob, dag, monkeypatch):
     """A collimated image (test/metamorphic_test/script.py's collimator alteration blacks out a frame): raw zeros give
     normalized 0, band 0 and — far enough inside — a reconstruction that is exactly 0, where the reference's histogram
