@@ -52,7 +52,7 @@ COLD_BUFFERS = 8          # 8 x (64 MB in + 16 MB out) = 640 MB rotating footpri
 COLD_ITERS = 64
 
 
-def algorithmic_bytes(n, levels, batch, fused_u16=True, fused_gradhist=False):
+def algorithmic_bytes(n, levels, batch, fused_u16=True, fused_gradhist=False, fused_rb=False):
     """Algorithmic HBM bytes per launch of each kernel family, f32 = 4 B, u16 = 2 B.
     fused_u16: the level-0 kernels read the raw uint16 pixels (2 B/px) instead of a stored normalized image (4 B/px)."""
     src = 2 if fused_u16 else 4
@@ -64,7 +64,8 @@ def algorithmic_bytes(n, levels, batch, fused_u16=True, fused_gradhist=False):
     return {
         "minmax": 2 * p[0] * batch,
         "normalize": 6 * p[0] * batch,
-        "reduce_l0": (src * p[0] + 4 * p[1]) * batch,                    # read S^2 once (u16 when fused), write (S/2)^2 f32 once
+        "reduce_l0": ((src + 4) * p[0] + 4 * p[1]) * batch if fused_rb else (src * p[0] + 4 * p[1]) * batch,   # read S^2 once (u16 when fused), write (S/2)^2 f32 once
+                                                                         # (+ the band image when reduce and band are one launch)
         "reduce_rest": sum(4 * p[i] + 4 * p[i + 1] for i in rest) * batch / max(1, len(rest)),
         "band_l0": ((src + 4) * p[0] + 4 * p[1]) * batch,                # read fine + coarse, write band
         "band_rest": sum(8 * p[i] + 4 * p[i + 1] for i in rest) * batch / max(1, len(rest)),
@@ -262,7 +263,7 @@ def main():
         mpix = world * batch * n * n * args.steps / 1e6
         ms_per_step = elapsed / args.steps * 1e3
         fused = (n % 8 == 0) and os.environ.get("MUSICA_U16", "1") != "0"
-        ab = algorithmic_bytes(n, levels, batch, fused, fused_gradhist=proc.fuses_gradhist())
+        ab = algorithmic_bytes(n, levels, batch, fused, fused_gradhist=proc.fuses_gradhist(), fused_rb=proc.fuses_reduce_band())
         kernels = {}
         total_kernel_us = 0.0
         for name, (us, cnt) in prof.items():
@@ -287,8 +288,9 @@ def main():
         if "reduce_l0" in kernels:
             k = kernels["reduce_l0"]
             pipeline_l0 = {"kernel": "%s (5-tap smooth + 2x downsample, level 0 of the pipeline, %d images of %dx%d per launch; input read as %s)"
-                                     % ("k_reduce_u16_pf" if fused else "k_reduce_fast_pf", batch, n, n,
-                                        "raw uint16 normalised on the fly: 2 B/px in + 1 B/px out" if fused else "f32: 4 B/px in + 1 B/px out"),
+                                     % ("k_reduce_band_u16 — smooth + downsample AND the band-pass image in one march" if proc.fuses_reduce_band() else
+                                        "k_reduce_u16_pf" if fused else "k_reduce_fast_pf", batch, n, n,
+                                        "raw uint16 normalised on the fly: 2 B/px in + 1 B/px (+ 4 B/px band) out" if fused else "f32: 4 B/px in + 1 B/px out"),
                            "bound": "hbm", "achieved": k["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(k["alg_GBps"] / HBM_PEAK_GBS, 4),
                            "traffic": traffic_doc.get(args.workload, {}).get("reduce_l0_hbm_bytes_per_launch"), "traffic_source": traffic_source,

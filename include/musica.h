@@ -165,6 +165,9 @@ uint32_t musica_get_batch(const musica_ctx* ctx);
 /* 1 when the level-0 expand launch of this context also accumulates the gradation histogram (no separate pass over the
  * reconstructed image; bench.py prices the launch accordingly), else 0. */
 int musica_fuses_gradation_histogram(const musica_ctx* ctx);
+/* 1 when level 0's smooth + downsample and band-pass image come out of one launch (k_reduce_band_u16; the `reduce_l0` profile
+ * family then covers both and `band_l0` stays empty), else 0. */
+int musica_fuses_reduce_band(const musica_ctx* ctx);
 uint32_t musica_get_level_size(const musica_ctx* ctx, uint32_t level);
 
 /* ---- the hot path ---------------------------------------------------- */

@@ -420,6 +420,135 @@ __global__ __launch_bounds__(kBlockThreads) void k_band_fast(const float* __rest
     }
 }
 
+// ======================================================================================
+// Level 0 in one march: K1 + K4 + K5 + K6 and K7 + K8 + K9 — smooth + downsample AND the band-pass image — from one read
+// of the raw pixels. Separately, k_reduce_u16_pf and k_band_fast<., true> each read and normalise the whole image
+// (2 x (2 B/px + ~14 instructions per pixel)) and the band launch reads the coarse image back (1 B/px); here a wavefront
+// that marches down its strip keeps the last three coarse rows it produced in registers and emits the band rows 2k, 2k+1
+// as soon as coarse row k+1 exists: 7 B/px instead of 3 + 7, one launch instead of two.
+// What a strip cannot take from its neighbours' registers it recomputes: the coarse rows k0-1 and k1 above / below its
+// segment (two extra fine rows at either end) and, on lane 0 / lane 63, the coarse column left / right of the strip
+// (four raw halo pixels per row instead of two / one). Every value is produced by the expressions of reduce_row() and
+// lowpass_pair(), so both outputs are bit-identical to the two-kernel path (tested against the oracle and against it).
+// ======================================================================================
+struct FRow {
+    float v[8];   // normalized pixels c .. c+7
+    float h[4];   // c-4 .. c-1 on lane 0, c+8 .. c+11 on lane 63 (strips with a neighbour on that side; 0 elsewhere)
+};
+struct RawF {
+    float4 m;     // 8 raw uint16 (bit pattern)
+    float2 h;     // 4 raw halo pixels
+};
+__device__ __forceinline__ void load_raw_f(RawF& r, const Buf& b, uint32_t row_off, uint32_t off, uint32_t off_h) {
+    r.m = bload4(b, off + row_off);
+    r.h = bload2(b, off_h + row_off);
+}
+__device__ __forceinline__ void convert_f(FRow& r, const RawF& w, const NormK& nk) {
+    norm8(r.v, w.m, nk);
+    const uint32_t a = __float_as_uint(w.h.x), b = __float_as_uint(w.h.y);
+    r.h[0] = norm_px(a & 0xFFFFu, nk);
+    r.h[1] = norm_px(a >> 16, nk);
+    r.h[2] = norm_px(b & 0xFFFFu, nk);
+    r.h[3] = norm_px(b >> 16, nk);
+}
+// One coarse row (the lane's 4 columns + the halo column of an edge lane) from its five fine rows: reduce_row()'s arithmetic.
+__device__ __forceinline__ void coarse_row(CRow& cr, const FRow& r0, const FRow& r1, const FRow& r2, const FRow& r3, const FRow& r4, const LaneCfg& g) {
+    float v[8], vh[4];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = chain5(r0.v[j], r1.v[j], r2.v[j], r3.v[j], r4.v[j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) vh[j] = chain5(r0.h[j], r1.h[j], r2.h[j], r3.h[j], r4.h[j]);
+    float vl6 = from_left_lane(v[6]);
+    float vl7 = from_left_lane(v[7]);
+    float vr0 = from_right_lane(v[0]);
+    if (g.lane0) {
+        vl6 = g.left_mirror ? v[2] : vh[2];  // column -2 -> 2, -1 -> 1 (img_smooth.comp:13); else columns c-2, c-1
+        vl7 = g.left_mirror ? v[1] : vh[3];
+    }
+    if (g.last_active) vr0 = v[6];           // column S -> S-2 (img_smooth.comp:12)
+    else if (g.lane63) vr0 = vh[0];          // column c+8
+    cr.v[0] = chain5(vl6, vl7, v[0], v[1], v[2]);
+    cr.v[1] = chain5(v[0], v[1], v[2], v[3], v[4]);
+    cr.v[2] = chain5(v[2], v[3], v[4], v[5], v[6]);
+    cr.v[3] = chain5(v[4], v[5], v[6], v[7], vr0);
+    // the coarse column next to the strip: j0-1 (fine c-4 .. c) on lane 0, j0+4 (fine c+6 .. c+10) on lane 63 — what the
+    // neighbouring strip's edge lane computes as its own column
+    const bool r = g.lane63;
+    const float ch = chain5(r ? v[6] : vh[0], r ? v[7] : vh[1], r ? vh[0] : vh[2], r ? vh[1] : vh[3], r ? vh[2] : v[0]);
+    cr.hl = ch;
+    cr.hr = ch;
+}
+__device__ __forceinline__ void band_pair(const CRow& a, const CRow& b, const CRow& c, const FRow& fe, const FRow& fo, const LaneCfg& g,
+                                          const Buf& bb, uint32_t off_e, uint32_t off_o) {
+    float lowE[8], lowO[8], be[8], bo[8];
+    lowpass_pair(a, b, c, g, lowE, lowO);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        be[j] = fe.v[j] - lowE[j];   // img_difference.comp:15
+        bo[j] = fo.v[j] - lowO[j];
+    }
+    store8(bb, g.off + off_e, be);
+    store8(bb, g.off + off_o, bo);
+}
+
+// rows_per_wave counts coarse rows. grid: x = strips, y = ceil(segments / 4), z = batch.
+__global__ __launch_bounds__(kBlockThreads) void k_reduce_band_u16(const uint16_t* __restrict__ px, float* __restrict__ down, float* __restrict__ band,
+                                                                   int S, int pitch, size_t plane, int Sc, int cpitch, size_t cplane,
+                                                                   int rows_per_wave, const uint32_t* __restrict__ minmax, int min_chain_exact) {
+    const int lane = threadIdx.x & 63;
+    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int k0 = seg * rows_per_wave;
+    if (k0 >= Sc) return;  // wave-uniform
+    const int k1 = min(k0 + rows_per_wave, Sc);
+    const int img = blockIdx.z;
+    float minv, maxv;
+    chain_scalars(minmax, img, min_chain_exact, minv, maxv);
+    const NormK nk = make_norm(minv, maxv);
+    const Buf ib = make_buf(px + (size_t)img * S * S, (size_t)S * S * 2);
+    const Buf db = make_buf(down + (size_t)img * cplane, cplane * 4);
+    const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
+    const LaneCfg g = make_cfg(blockIdx.x, lane, S);
+    const uint32_t uoff = g.off == kOob ? kOob : g.off >> 1;
+    // four halo pixels: c-4 .. c-1 (lane 0 of a strip that is not the first) or c+8 .. c+11 (lane 63 with more image to its right)
+    const uint32_t uoff_h = g.off_l != kOob ? (uint32_t)(g.c - 4) * 2u : (g.off_r != kOob ? (uint32_t)(g.c + 8) * 2u : kOob);
+    const int hi = S - 1;
+    const uint32_t urb = (uint32_t)S * 2u, rb = (uint32_t)pitch * 4u, crb = (uint32_t)cpitch * 4u;
+    const int ks = max(k0 - 1, 0), ke = min(k1, Sc - 1);   // coarse rows this wavefront computes (the first / last only feed its band rows)
+
+    FRow w0, w1, w2, w3, w4;
+    RawF ra, rc;
+    load_raw_f(ra, ib, (uint32_t)mirror_idx(2 * ks - 2, hi) * urb, uoff, uoff_h);
+    convert_f(w0, ra, nk);
+    load_raw_f(ra, ib, (uint32_t)mirror_idx(2 * ks - 1, hi) * urb, uoff, uoff_h);
+    convert_f(w1, ra, nk);
+    load_raw_f(ra, ib, (uint32_t)(2 * ks) * urb, uoff, uoff_h);
+    convert_f(w2, ra, nk);
+    load_raw_f(ra, ib, (uint32_t)mirror_idx(2 * ks + 1, hi) * urb, uoff, uoff_h);
+    load_raw_f(rc, ib, (uint32_t)mirror_idx(2 * ks + 2, hi) * urb, uoff, uoff_h);
+    CRow c0, cm1, cm2;
+    cm1 = CRow(); cm2 = CRow();
+    for (int k = ks; k <= ke; k++) {
+        convert_f(w3, ra, nk);   // the pair requested one trip ago
+        convert_f(w4, rc, nk);
+        const int kn = min(k + 1, ke);
+        load_raw_f(ra, ib, (uint32_t)mirror_idx(2 * kn + 1, hi) * urb, uoff, uoff_h);
+        load_raw_f(rc, ib, (uint32_t)mirror_idx(2 * kn + 2, hi) * urb, uoff, uoff_h);
+        coarse_row(c0, w0, w1, w2, w3, w4, g);
+        if (k >= k0 && k < k1)  // wave-uniform
+            bstore4(db, g.coff + (uint32_t)k * crb, make_float4(c0.v[0], c0.v[1], c0.v[2], c0.v[3]));
+        // coarse row k completes the neighbourhood of row k-1: band rows 2(k-1), 2(k-1)+1 are the two oldest rows of the window.
+        // km1(0) = coarse_of_fine(-2) = 1 (reflect-101 on the fine grid, img_smooth_upsampled.comp:10-16): row k itself.
+        const int kp = k - 1;
+        if (kp >= k0 && kp < k1)  // wave-uniform
+            band_pair(kp == 0 ? c0 : cm2, cm1, c0, w0, w1, g, bb, (uint32_t)(2 * kp) * rb, (uint32_t)(2 * kp + 1) * rb);
+        cm2 = cm1; cm1 = c0;
+        w0 = w2; w1 = w3; w2 = w4;
+    }
+    // the last row pair of the image: kp1(Sc-1) = coarse_of_fine(S) = Sc-1 (fine row S mirrors onto S-2)
+    if (k1 == Sc)
+        band_pair(cm2, cm1, cm1, w0, w1, g, bb, (uint32_t)(2 * (Sc - 1)) * rb, (uint32_t)(2 * (Sc - 1) + 1) * rb);
+}
+
 // lowpass value at fine (x, y) for any S (generic form).
 __device__ __forceinline__ float lowpass_generic(const float* __restrict__ coarse, int cpitch, int Sc, int S, int x, int y) {
     float V[5];
@@ -770,6 +899,11 @@ void launch_reduce_u16(hipStream_t st, const uint16_t* px, const LevelDesc& li, 
                        const uint32_t* minmax, int min_chain_exact) {
     hipLaunchKernelGGL(k_reduce_u16_pf, stream_grid(li.S, lo.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, px, out, li.S, lo.S, lo.pitch,
                        lo.plane, rows_per_wave, minmax, min_chain_exact);
+}
+void launch_reduce_band_u16(hipStream_t st, const uint16_t* px, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
+                            int rows_per_wave, const uint32_t* minmax, int min_chain_exact) {
+    hipLaunchKernelGGL(k_reduce_band_u16, stream_grid(lf.S, lc.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, px, down, band, lf.S, lf.pitch,
+                       lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
 }
 void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                      int rows_per_wave, int rows_per_trip, const uint32_t* minmax, int min_chain_exact) {

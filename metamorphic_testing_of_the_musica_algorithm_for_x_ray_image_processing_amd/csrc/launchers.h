@@ -61,6 +61,8 @@ void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* 
 void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave, bool force_generic, int rows_per_trip);
 void launch_reduce_u16(hipStream_t st, const uint16_t* px, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave,
                        const uint32_t* minmax, int min_chain_exact);
+void launch_reduce_band_u16(hipStream_t st, const uint16_t* px, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
+                            int rows_per_wave, const uint32_t* minmax, int min_chain_exact);
 void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                      int rows_per_wave, int rows_per_trip, const uint32_t* minmax, int min_chain_exact);
 void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch);

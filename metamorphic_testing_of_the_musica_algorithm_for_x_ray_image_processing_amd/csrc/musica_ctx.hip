@@ -99,6 +99,8 @@ struct musica_ctx {
     uint32_t* d_gzero;         // [B]: that condition
     int* d_thr090;             // [B]: raw-pixel form of `normalized <= 0.9`
     bool fuse_gh;              // the level-0 expand launch accumulates the gradation histogram
+    bool fuse_rb;              // level 0: smooth + downsample and the band-pass image in one launch (k_reduce_band_u16)
+    int rows_rb;               // its coarse rows per wavefront
     musica_hist_max_point* d_grad_max;
     DevCurve* d_gcurve;
     float* d_graded;
@@ -211,6 +213,7 @@ static void copy_rows(musica_ctx* dst, const musica_ctx* src) {
     memcpy(dst->rows_band, src->rows_band, sizeof(src->rows_band));
     memcpy(dst->rows_expand, src->rows_expand, sizeof(src->rows_expand));
     memcpy(dst->rows_sdev, src->rows_sdev, sizeof(src->rows_sdev));
+    dst->rows_rb = src->rows_rb;
 }
 
 // Shallow copy of the parent restricted to images [i0, i0 + nb): same buffers, pointers moved to the first image.
@@ -417,6 +420,8 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->graph_next = 0;
     c->fuse_u16 = env_int("MUSICA_U16", 1) != 0 && (N % 8) == 0 && !(params->flags & MUSICA_FLAG_GENERIC_KERNELS);
     c->norm_valid = false;
+    c->fuse_rb = env_int("MUSICA_FUSE_RB", 1) != 0 && c->fuse_u16;
+    c->rows_rb = 16;
     // fused gradation histogram: streaming level-0 kernels on raw pixels, cnr scale 8 (every N >= 57 with N % 8 == 0), no CLAHE
     // block (it wants the stored relevant image anyway)
     c->fuse_gh = env_int("MUSICA_FUSE_GH", 1) != 0 && c->fuse_u16 && !(params->flags & MUSICA_FLAG_CLAHE) &&
@@ -488,6 +493,7 @@ uint32_t musica_get_image_size(const musica_ctx* c) { return c ? (uint32_t)c->N 
 uint32_t musica_get_levels(const musica_ctx* c) { return c ? (uint32_t)c->L : 0; }
 uint32_t musica_get_batch(const musica_ctx* c) { return c ? (uint32_t)c->B : 0; }
 int musica_fuses_gradation_histogram(const musica_ctx* c) { return (c && c->fuse_gh && !c->generic) ? 1 : 0; }
+int musica_fuses_reduce_band(const musica_ctx* c) { return (c && c->fuse_rb) ? 1 : 0; }
 uint32_t musica_get_level_size(const musica_ctx* c, uint32_t level) { return (c && (int)level <= c->L) ? (uint32_t)c->lv[level].S : 0; }
 
 }  // extern "C"
@@ -563,6 +569,10 @@ static void run_reduce_level(musica_ctx* c, int i, int rows) {
     }
     launch_reduce(c->cur, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, rows, c->generic, c->tuning ? 3 : (i == 0 ? 0 : 1));
 }
+// level 0: reduce + band in one launch
+static void run_reduce_band0(musica_ctx* c, int /*level*/, int rows) {
+    launch_reduce_band_u16(c->cur, c->cur_input, c->d_down[0], c->d_band[0], c->lv[0], c->lv[1], c->B, rows, c->d_minmax, c->min_chain_exact);
+}
 static void run_band_level(musica_ctx* c, int i, int rows) {
     if (i == 0 && c->fuse_u16) {
         launch_band_u16(c->cur, c->cur_input, c->d_down[0], c->d_band[0], c->lv[0], c->lv[1], c->B, rows, c->band_trip, c->d_minmax, c->min_chain_exact);
@@ -578,6 +588,7 @@ static void run_sdev_level(musica_ctx* c, int i, int rows) {
 // stage "red" (src/vk_processing.cpp:2233-2273)
 static void enqueue_reduce(musica_ctx* c) {
     for (int i = 0; i < c->L; i++) {
+        if (i == 0 && c->fuse_rb) { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_band0(c, 0, c->rows_rb); continue; }
         { Span sp(c, i == 0 ? MUSICA_KERNEL_REDUCE_L0 : MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
         { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
     }
@@ -706,13 +717,14 @@ static void enqueue_dag(musica_ctx* c) {
     c->cur = c->stream;
     launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B, c->d_grad_hist_b, c->d_gzero);  // :2153-2162
     enqueue_norm(c);
-    { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_level(c, 0, c->rows_reduce[0]); }
+    if (c->fuse_rb) { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_band0(c, 0, c->rows_rb); }   // reduce 0 + band 0 in one march
+    else { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_level(c, 0, c->rows_reduce[0]); }
     { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, 1, c->rows_reduce[1]); }
     hipEventRecord(c->ev_fork, c->stream);
     hipStreamWaitEvent(c->side, c->ev_fork, 0);
     c->cur = c->stream;
     for (int i = 0; i < 2; i++) {
-        { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
+        if (!(i == 0 && c->fuse_rb)) { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
         { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
     }
     c->cur = c->side;
@@ -871,7 +883,9 @@ static void autotune(musica_ctx* c) {
     static const int cand_sdev[] = {16, 32, 64};
     for (int i = 0; i < c->L; i++) {
         if (c->lv[i].S < 512 || (c->lv[i].S % 8) != 0) continue;   // small levels are launch-bound: keep the heuristic
-        struct { int* slot; const int* cand; int ncand; void (*fn)(musica_ctx*, int, int); bool use; } jobs[4] = {
+        static const int cand_rb[] = {8, 16, 32, 64};
+        struct { int* slot; const int* cand; int ncand; void (*fn)(musica_ctx*, int, int); bool use; } jobs[5] = {
+            {&c->rows_rb, cand_rb, 4, run_reduce_band0, i == 0 && c->fuse_rb},
             {&c->rows_reduce[i], cand_reduce, 5, run_reduce_level, true},
             {&c->rows_band[i], cand_pair, 4, run_band_level, true},
             {&c->rows_expand[i], cand_pair, 4, run_expand_level, true},

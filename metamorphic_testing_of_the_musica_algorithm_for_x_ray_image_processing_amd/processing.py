@@ -99,6 +99,7 @@ ABI = {
     "musica_get_batch": (C.c_uint32, [_VP]),
     "musica_get_level_size": (C.c_uint32, [_VP, C.c_uint32]),
     "musica_fuses_gradation_histogram": (C.c_int, [_VP]),
+    "musica_fuses_reduce_band": (C.c_int, [_VP]),
     "musica_execute": (C.c_int, [_VP, _U16P]),
     "musica_execute_device": (C.c_int, [_VP, _VP]),
     "musica_execute_stream": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, C.POINTER(Stats)]),
@@ -383,6 +384,10 @@ class MusicaProcessing:
     def fuses_gradhist(self):
         """True when the level-0 expand kernel also accumulates the gradation histogram (no separate k_grad_hist launch)."""
         return self._lib.musica_fuses_gradation_histogram(self._h) == 1
+
+    def fuses_reduce_band(self):
+        """True when level 0's reduce and band kernels are one launch (profile family `reduce_l0` covers both)."""
+        return self._lib.musica_fuses_reduce_band(self._h) == 1
 
     # ---- profiling ----------------------------------------------------------------------
     def profile_enable(self, which=True):
