@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_band_fast(const float* __rest
 
 // ======================================================================================
 // Level 0 in one march: K1 + K4 + K5 + K6 and K7 + K8 + K9 — smooth + downsample AND the band-pass image — from one read
-// of the raw pixels. Separately, k_reduce_u16_pf and k_band_fast<., true> each read and normalise the whole image
+// of the fine image. Separately, k_reduce_u16_pf and k_band_fast<., true> each read and normalise the whole image
 // (2 x (2 B/px + ~14 instructions per pixel)) and the band launch reads the coarse image back (1 B/px); here a wavefront
 // that marches down its strip keeps the last three coarse rows it produced in registers and emits the band rows 2k, 2k+1
 // as soon as coarse row k+1 exists: 7 B/px instead of 3 + 7, one launch instead of two.
@@ -491,48 +491,74 @@ __device__ __forceinline__ void band_pair(const CRow& a, const CRow& b, const CR
     store8(bb, g.off + off_o, bo);
 }
 
+__device__ __forceinline__ void load_f(FRow& r, const Buf& b, uint32_t row_off, uint32_t off, uint32_t off_h) {
+    load8(r.v, b, off + row_off);
+    const float4 h = bload4(b, off_h + row_off);
+    r.h[0] = h.x; r.h[1] = h.y; r.h[2] = h.z; r.h[3] = h.w;
+}
+
 // rows_per_wave counts coarse rows. grid: x = strips, y = ceil(segments / 4), z = batch.
-__global__ __launch_bounds__(kBlockThreads) void k_reduce_band_u16(const uint16_t* __restrict__ px, float* __restrict__ down, float* __restrict__ band,
-                                                                   int S, int pitch, size_t plane, int Sc, int cpitch, size_t cplane,
-                                                                   int rows_per_wave, const uint32_t* __restrict__ minmax, int min_chain_exact) {
+// U16: the fine image is the raw uint16 input, normalised on the fly (level 0); the two rows of the next trip are requested as
+// raw pixels (6 registers) one trip ahead. Otherwise the fine image is f32 (levels >= 1): the rows are loaded where they are
+// needed (a prefetch would cost 24 registers and a wavefront per SIMD; these levels are small and L2-resident).
+template <bool U16>
+__global__ __launch_bounds__(kBlockThreads) void k_reduce_band(const void* __restrict__ fine, float* __restrict__ down, float* __restrict__ band,
+                                                               int S, int pitch, size_t plane, int Sc, int cpitch, size_t cplane,
+                                                               int rows_per_wave, const uint32_t* __restrict__ minmax, int min_chain_exact) {
     const int lane = threadIdx.x & 63;
     const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
     const int k0 = seg * rows_per_wave;
     if (k0 >= Sc) return;  // wave-uniform
     const int k1 = min(k0 + rows_per_wave, Sc);
     const int img = blockIdx.z;
-    float minv, maxv;
-    chain_scalars(minmax, img, min_chain_exact, minv, maxv);
-    const NormK nk = make_norm(minv, maxv);
-    const Buf ib = make_buf(px + (size_t)img * S * S, (size_t)S * S * 2);
+    NormK nk = make_norm(0.0f, 1.0f);
+    if (U16) {
+        float minv, maxv;
+        chain_scalars(minmax, img, min_chain_exact, minv, maxv);
+        nk = make_norm(minv, maxv);
+    }
+    const Buf ib = U16 ? make_buf(reinterpret_cast<const uint16_t*>(fine) + (size_t)img * S * S, (size_t)S * S * 2)
+                       : make_buf(reinterpret_cast<const float*>(fine) + (size_t)img * plane, plane * 4);
     const Buf db = make_buf(down + (size_t)img * cplane, cplane * 4);
     const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
     const LaneCfg g = make_cfg(blockIdx.x, lane, S);
-    const uint32_t uoff = g.off == kOob ? kOob : g.off >> 1;
-    // four halo pixels: c-4 .. c-1 (lane 0 of a strip that is not the first) or c+8 .. c+11 (lane 63 with more image to its right)
-    const uint32_t uoff_h = g.off_l != kOob ? (uint32_t)(g.c - 4) * 2u : (g.off_r != kOob ? (uint32_t)(g.c + 8) * 2u : kOob);
+    // own pixels and four halo pixels: c-4 .. c-1 (lane 0 of a strip that is not the first) or c+8 .. c+11 (lane 63 with more image to its right)
+    const uint32_t px_bytes = U16 ? 2u : 4u;
+    const uint32_t foff = g.off == kOob ? kOob : (uint32_t)g.c * px_bytes;
+    const uint32_t foff_h = g.off_l != kOob ? (uint32_t)(g.c - 4) * px_bytes : (g.off_r != kOob ? (uint32_t)(g.c + 8) * px_bytes : kOob);
     const int hi = S - 1;
-    const uint32_t urb = (uint32_t)S * 2u, rb = (uint32_t)pitch * 4u, crb = (uint32_t)cpitch * 4u;
+    const uint32_t frb = U16 ? (uint32_t)S * 2u : (uint32_t)pitch * 4u, rb = (uint32_t)pitch * 4u, crb = (uint32_t)cpitch * 4u;
     const int ks = max(k0 - 1, 0), ke = min(k1, Sc - 1);   // coarse rows this wavefront computes (the first / last only feed its band rows)
 
     FRow w0, w1, w2, w3, w4;
     RawF ra, rc;
-    load_raw_f(ra, ib, (uint32_t)mirror_idx(2 * ks - 2, hi) * urb, uoff, uoff_h);
-    convert_f(w0, ra, nk);
-    load_raw_f(ra, ib, (uint32_t)mirror_idx(2 * ks - 1, hi) * urb, uoff, uoff_h);
-    convert_f(w1, ra, nk);
-    load_raw_f(ra, ib, (uint32_t)(2 * ks) * urb, uoff, uoff_h);
-    convert_f(w2, ra, nk);
-    load_raw_f(ra, ib, (uint32_t)mirror_idx(2 * ks + 1, hi) * urb, uoff, uoff_h);
-    load_raw_f(rc, ib, (uint32_t)mirror_idx(2 * ks + 2, hi) * urb, uoff, uoff_h);
+    if (U16) {
+        load_raw_f(ra, ib, (uint32_t)mirror_idx(2 * ks - 2, hi) * frb, foff, foff_h);
+        convert_f(w0, ra, nk);
+        load_raw_f(ra, ib, (uint32_t)mirror_idx(2 * ks - 1, hi) * frb, foff, foff_h);
+        convert_f(w1, ra, nk);
+        load_raw_f(ra, ib, (uint32_t)(2 * ks) * frb, foff, foff_h);
+        convert_f(w2, ra, nk);
+        load_raw_f(ra, ib, (uint32_t)mirror_idx(2 * ks + 1, hi) * frb, foff, foff_h);
+        load_raw_f(rc, ib, (uint32_t)mirror_idx(2 * ks + 2, hi) * frb, foff, foff_h);
+    } else {
+        load_f(w0, ib, (uint32_t)mirror_idx(2 * ks - 2, hi) * frb, foff, foff_h);
+        load_f(w1, ib, (uint32_t)mirror_idx(2 * ks - 1, hi) * frb, foff, foff_h);
+        load_f(w2, ib, (uint32_t)(2 * ks) * frb, foff, foff_h);
+    }
     CRow c0, cm1, cm2;
     cm1 = CRow(); cm2 = CRow();
     for (int k = ks; k <= ke; k++) {
-        convert_f(w3, ra, nk);   // the pair requested one trip ago
-        convert_f(w4, rc, nk);
-        const int kn = min(k + 1, ke);
-        load_raw_f(ra, ib, (uint32_t)mirror_idx(2 * kn + 1, hi) * urb, uoff, uoff_h);
-        load_raw_f(rc, ib, (uint32_t)mirror_idx(2 * kn + 2, hi) * urb, uoff, uoff_h);
+        if (U16) {
+            convert_f(w3, ra, nk);   // the pair requested one trip ago
+            convert_f(w4, rc, nk);
+            const int kn = min(k + 1, ke);
+            load_raw_f(ra, ib, (uint32_t)mirror_idx(2 * kn + 1, hi) * frb, foff, foff_h);
+            load_raw_f(rc, ib, (uint32_t)mirror_idx(2 * kn + 2, hi) * frb, foff, foff_h);
+        } else {
+            load_f(w3, ib, (uint32_t)mirror_idx(2 * k + 1, hi) * frb, foff, foff_h);
+            load_f(w4, ib, (uint32_t)mirror_idx(2 * k + 2, hi) * frb, foff, foff_h);
+        }
         coarse_row(c0, w0, w1, w2, w3, w4, g);
         if (k >= k0 && k < k1)  // wave-uniform
             bstore4(db, g.coff + (uint32_t)k * crb, make_float4(c0.v[0], c0.v[1], c0.v[2], c0.v[3]));
@@ -902,8 +928,13 @@ void launch_reduce_u16(hipStream_t st, const uint16_t* px, const LevelDesc& li, 
 }
 void launch_reduce_band_u16(hipStream_t st, const uint16_t* px, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                             int rows_per_wave, const uint32_t* minmax, int min_chain_exact) {
-    hipLaunchKernelGGL(k_reduce_band_u16, stream_grid(lf.S, lc.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, px, down, band, lf.S, lf.pitch,
-                       lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
+    hipLaunchKernelGGL(k_reduce_band<true>, stream_grid(lf.S, lc.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, (const void*)px, down, band, lf.S,
+                       lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
+}
+// levels >= 1 (f32 fine image); the side must be a multiple of 8 and at least 16 (the caller checks)
+void launch_reduce_band(hipStream_t st, const float* fine, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave) {
+    hipLaunchKernelGGL(k_reduce_band<false>, stream_grid(lf.S, lc.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, (const void*)fine, down, band, lf.S,
+                       lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, (const uint32_t*)nullptr, 0);
 }
 void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                      int rows_per_wave, int rows_per_trip, const uint32_t* minmax, int min_chain_exact) {

@@ -63,6 +63,7 @@ void launch_reduce_u16(hipStream_t st, const uint16_t* px, const LevelDesc& li, 
                        const uint32_t* minmax, int min_chain_exact);
 void launch_reduce_band_u16(hipStream_t st, const uint16_t* px, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                             int rows_per_wave, const uint32_t* minmax, int min_chain_exact);
+void launch_reduce_band(hipStream_t st, const float* fine, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave);
 void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                      int rows_per_wave, int rows_per_trip, const uint32_t* minmax, int min_chain_exact);
 void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch);

@@ -99,8 +99,9 @@ struct musica_ctx {
     uint32_t* d_gzero;         // [B]: that condition
     int* d_thr090;             // [B]: raw-pixel form of `normalized <= 0.9`
     bool fuse_gh;              // the level-0 expand launch accumulates the gradation histogram
-    bool fuse_rb;              // level 0: smooth + downsample and the band-pass image in one launch (k_reduce_band_u16)
-    int rows_rb;               // its coarse rows per wavefront
+    int fuse_rb;               // smooth + downsample and the band-pass image of a level in one launch (k_reduce_band): 0 off, 1 level 0 only,
+                               // 2 every level whose side is a multiple of 8
+    int rows_rb[MUSICA_MAX_LEVELS];   // its coarse rows per wavefront
     musica_hist_max_point* d_grad_max;
     DevCurve* d_gcurve;
     float* d_graded;
@@ -176,6 +177,7 @@ static musica_nr_params host_nr_params(uint32_t i) {
 }
 
 static void autotune(musica_ctx* c);
+static bool rb_level(const musica_ctx* c, int i);
 
 static uint32_t cnr_scale(int S, int cnrS) { return (uint32_t)ceilf((float)S / (float)cnrS); }  // noise_reduction.comp:38
 
@@ -213,7 +215,7 @@ static void copy_rows(musica_ctx* dst, const musica_ctx* src) {
     memcpy(dst->rows_band, src->rows_band, sizeof(src->rows_band));
     memcpy(dst->rows_expand, src->rows_expand, sizeof(src->rows_expand));
     memcpy(dst->rows_sdev, src->rows_sdev, sizeof(src->rows_sdev));
-    dst->rows_rb = src->rows_rb;
+    memcpy(dst->rows_rb, src->rows_rb, sizeof(src->rows_rb));
 }
 
 // Shallow copy of the parent restricted to images [i0, i0 + nb): same buffers, pointers moved to the first image.
@@ -264,6 +266,7 @@ static musica_ctx* make_view(const musica_ctx* c, int i0, int nb) {
         v->rows_band[i] = pick_rows(c->band_rows, 1, c->lv[i].S, c->lv[i + 1].S, nb);
         v->rows_expand[i] = pick_rows(c->expand_rows, 1, c->lv[i].S, c->lv[i + 1].S, nb);
         if (i <= MUSICA_CNR_LEVEL) v->rows_sdev[i] = pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, nb);
+        v->rows_rb[i] = pick_rows(16, 1, c->lv[i].S, c->lv[i + 1].S, nb);
     }
     return v;
 }
@@ -420,8 +423,8 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->graph_next = 0;
     c->fuse_u16 = env_int("MUSICA_U16", 1) != 0 && (N % 8) == 0 && !(params->flags & MUSICA_FLAG_GENERIC_KERNELS);
     c->norm_valid = false;
-    c->fuse_rb = env_int("MUSICA_FUSE_RB", 1) != 0 && c->fuse_u16;
-    c->rows_rb = 16;
+    c->fuse_rb = c->generic ? 0 : env_int("MUSICA_FUSE_RB", 2);
+    if (!c->fuse_u16 && c->fuse_rb == 1) c->fuse_rb = 0;
     // fused gradation histogram: streaming level-0 kernels on raw pixels, cnr scale 8 (every N >= 57 with N % 8 == 0), no CLAHE
     // block (it wants the stored relevant image anyway)
     c->fuse_gh = env_int("MUSICA_FUSE_GH", 1) != 0 && c->fuse_u16 && !(params->flags & MUSICA_FLAG_CLAHE) &&
@@ -470,6 +473,7 @@ static musica_ctx* create_impl(const musica_params* params) {
         c->rows_band[i] = pick_rows(c->band_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
         c->rows_expand[i] = pick_rows(c->expand_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
         if (i <= MUSICA_CNR_LEVEL) c->rows_sdev[i] = pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, c->B);
+        c->rows_rb[i] = pick_rows(16, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
     }
     const bool tune = !(params->flags & MUSICA_FLAG_NO_AUTOTUNE) && env_int("MUSICA_AUTOTUNE", 1) && !c->generic;
     const int groups = pick_groups(c);
@@ -493,7 +497,7 @@ uint32_t musica_get_image_size(const musica_ctx* c) { return c ? (uint32_t)c->N 
 uint32_t musica_get_levels(const musica_ctx* c) { return c ? (uint32_t)c->L : 0; }
 uint32_t musica_get_batch(const musica_ctx* c) { return c ? (uint32_t)c->B : 0; }
 int musica_fuses_gradation_histogram(const musica_ctx* c) { return (c && c->fuse_gh && !c->generic) ? 1 : 0; }
-int musica_fuses_reduce_band(const musica_ctx* c) { return (c && c->fuse_rb) ? 1 : 0; }
+int musica_fuses_reduce_band(const musica_ctx* c) { return (c && rb_level(c, 0)) ? 1 : 0; }
 uint32_t musica_get_level_size(const musica_ctx* c, uint32_t level) { return (c && (int)level <= c->L) ? (uint32_t)c->lv[level].S : 0; }
 
 }  // extern "C"
@@ -569,9 +573,16 @@ static void run_reduce_level(musica_ctx* c, int i, int rows) {
     }
     launch_reduce(c->cur, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, rows, c->generic, c->tuning ? 3 : (i == 0 ? 0 : 1));
 }
-// level 0: reduce + band in one launch
-static void run_reduce_band0(musica_ctx* c, int /*level*/, int rows) {
-    launch_reduce_band_u16(c->cur, c->cur_input, c->d_down[0], c->d_band[0], c->lv[0], c->lv[1], c->B, rows, c->d_minmax, c->min_chain_exact);
+// reduce + band of a level in one launch
+static bool rb_level(const musica_ctx* c, int i) {
+    if (c->generic || c->lv[i].S < 8 || (c->lv[i].S % 8) != 0) return false;
+    return i == 0 ? (c->fuse_rb >= 1 && (c->fuse_u16 || c->fuse_rb >= 2)) : c->fuse_rb >= 2;
+}
+static void run_reduce_band(musica_ctx* c, int i, int rows) {
+    if (i == 0 && c->fuse_u16)
+        launch_reduce_band_u16(c->cur, c->cur_input, c->d_down[0], c->d_band[0], c->lv[0], c->lv[1], c->B, rows, c->d_minmax, c->min_chain_exact);
+    else
+        launch_reduce_band(c->cur, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, rows);
 }
 static void run_band_level(musica_ctx* c, int i, int rows) {
     if (i == 0 && c->fuse_u16) {
@@ -580,6 +591,12 @@ static void run_band_level(musica_ctx* c, int i, int rows) {
     }
     launch_band(c->cur, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, rows, c->generic, c->band_trip);
 }
+// reduce and band of level i, as one launch where that form applies
+static void run_reduce_and_band(musica_ctx* c, int i) {
+    if (rb_level(c, i)) { Span sp(c, i == 0 ? MUSICA_KERNEL_REDUCE_L0 : MUSICA_KERNEL_REDUCE_REST); run_reduce_band(c, i, c->rows_rb[i]); return; }
+    { Span sp(c, i == 0 ? MUSICA_KERNEL_REDUCE_L0 : MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
+    { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
+}
 static void run_sdev_level(musica_ctx* c, int i, int rows) {
     launch_sdev_hist(c->cur, c->d_band[i], c->d_sdev[i], c->lv[i], c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS,
                      (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov, c->B, rows);
@@ -587,11 +604,7 @@ static void run_sdev_level(musica_ctx* c, int i, int rows) {
 
 // stage "red" (src/vk_processing.cpp:2233-2273)
 static void enqueue_reduce(musica_ctx* c) {
-    for (int i = 0; i < c->L; i++) {
-        if (i == 0 && c->fuse_rb) { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_band0(c, 0, c->rows_rb); continue; }
-        { Span sp(c, i == 0 ? MUSICA_KERNEL_REDUCE_L0 : MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
-        { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
-    }
+    for (int i = 0; i < c->L; i++) run_reduce_and_band(c, i);
 }
 
 // stage "anly" (src/vk_processing.cpp:2284-2357)
@@ -717,26 +730,28 @@ static void enqueue_dag(musica_ctx* c) {
     c->cur = c->stream;
     launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B, c->d_grad_hist_b, c->d_gzero);  // :2153-2162
     enqueue_norm(c);
-    if (c->fuse_rb) { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_band0(c, 0, c->rows_rb); }   // reduce 0 + band 0 in one march
+    // reduce (+ band, where the fused march applies: k_reduce_band) of levels 0 and 1
+    const bool rb0 = rb_level(c, 0), rb1 = rb_level(c, 1);
+    if (rb0) { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_band(c, 0, c->rows_rb[0]); }
     else { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_level(c, 0, c->rows_reduce[0]); }
-    { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, 1, c->rows_reduce[1]); }
+    if (rb1) { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_band(c, 1, c->rows_rb[1]); }
+    else { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, 1, c->rows_reduce[1]); }
     hipEventRecord(c->ev_fork, c->stream);
     hipStreamWaitEvent(c->side, c->ev_fork, 0);
     c->cur = c->stream;
     for (int i = 0; i < 2; i++) {
-        if (!(i == 0 && c->fuse_rb)) { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
+        if (!(i == 0 ? rb0 : rb1)) { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
         { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
     }
     c->cur = c->side;
-    for (int i = 2; i < L; i++) { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
-    for (int i = 2; i <= MUSICA_CNR_LEVEL; i++) { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
+    for (int i = 2; i <= MUSICA_CNR_LEVEL; i++) run_reduce_and_band(c, i);
     hipEventRecord(c->ev_s2, c->side);   // band 2 (and 3) exist
     hipStreamWaitEvent(c->side1, c->ev_s2, 0);
     c->cur = c->side1;
     { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, 2, c->rows_sdev[2]); }
     hipEventRecord(c->ev_s1, c->side1);
     c->cur = c->side;
-    for (int i = MUSICA_CNR_LEVEL + 1; i < L; i++) { Span sp(c, MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
+    for (int i = MUSICA_CNR_LEVEL + 1; i < L; i++) run_reduce_and_band(c, i);
     for (int lvl = L - 1; lvl > MUSICA_CNR_LEVEL; lvl--) {
         Span sp(c, MUSICA_KERNEL_EXPAND_REST);
         run_expand_level(c, lvl, c->rows_expand[lvl]);
@@ -883,11 +898,11 @@ static void autotune(musica_ctx* c) {
     static const int cand_sdev[] = {16, 32, 64};
     for (int i = 0; i < c->L; i++) {
         if (c->lv[i].S < 512 || (c->lv[i].S % 8) != 0) continue;   // small levels are launch-bound: keep the heuristic
-        static const int cand_rb[] = {8, 16, 32, 64};
+        static const int cand_rb[] = {4, 8, 16, 32, 64};
         struct { int* slot; const int* cand; int ncand; void (*fn)(musica_ctx*, int, int); bool use; } jobs[5] = {
-            {&c->rows_rb, cand_rb, 4, run_reduce_band0, i == 0 && c->fuse_rb},
-            {&c->rows_reduce[i], cand_reduce, 5, run_reduce_level, true},
-            {&c->rows_band[i], cand_pair, 4, run_band_level, true},
+            {&c->rows_rb[i], cand_rb, 5, run_reduce_band, rb_level(c, i)},
+            {&c->rows_reduce[i], cand_reduce, 5, run_reduce_level, !rb_level(c, i)},
+            {&c->rows_band[i], cand_pair, 4, run_band_level, !rb_level(c, i)},
             {&c->rows_expand[i], cand_pair, 4, run_expand_level, true},
             {i <= MUSICA_CNR_LEVEL ? &c->rows_sdev[i] : nullptr, cand_sdev, 3, run_sdev_level, i <= MUSICA_CNR_LEVEL},
         };
