@@ -5,7 +5,10 @@
 
 One "step" = one pass of the whole hot path (minmax -> pyramid reduce -> analysis -> contrast /
 noise-reduction + expand -> gradation) over one batch of synthetic raw images already resident in
-HBM. Default workload C4 is BASELINE.json configs[3] seen from one GPU:
+HBM. Steps alternate over --in-flight contexts (default 3, batch.ShardPipeline: step s is enqueued on context s mod 3, each
+context with its own copy of the input, its own buffers and ONE in-order stream, so the chip-filling kernels of a step
+run in the part-idle phases of the two steps beside it); `one_context` in the JSON line is the same K steps on a single
+three-stream context, each step behind the previous one. Default workload C4 is BASELINE.json configs[3] seen from one GPU:
 8 independent 2048 x 2048 16-bit images, 6-level pyramid, per GPU and per step (weak scaling: at N = 8
 that is the 64-image batch, at N = 1 it is 8 x configs[1]). Image k of the N x 8 images of a step goes to
 rank k mod N (batch.assign_images) with no data-path collective; RCCL is used once, inside the
@@ -88,6 +91,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C4", type=str.upper, choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="contexts whose steps alternate (batch.ShardPipeline): step s runs on context s mod D, so the head of a step fills the "
+                         "part-idle tail of the one before; 1 = one context, every step behind the previous one")
     ap.add_argument("--batch", type=int, default=0, help="override the workload's images per GPU per step (experiments only)")
     ap.add_argument("--kernel-events", action="store_true",
                     help="bracket the level-0 metric kernel with HIP events inside the timed steps (forces eager launches: stream "
@@ -178,33 +184,50 @@ def main():
     assert len(image_ids) == batch
     px = np.stack([phantom(n, 100 + k, bits=bits) for k in image_ids])   # C4 uses default_rng(100 + k)
 
-    proc = mp.MusicaProcessing(device=local_rank)
-    if not proc.init(n, levels=levels, batch=batch, flags=flags):
-        raise SystemExit("musica_create failed: " + mp.last_error())
-    proc.upload(px)                                                # inputs resident in HBM before the timed region
+    depth = 1 if args.kernel_events else max(1, args.in_flight)   # events inside the timed steps need the one profiled context
+    try:
+        pipe = mb.ShardPipeline(n, levels=levels, batch=batch, depth=depth, flags=flags, device=local_rank)
+    except RuntimeError as e:
+        raise SystemExit(str(e))
+    pipe.upload(px)                                                # inputs resident in HBM (one copy per context) before the timed region
+    pipe.prime()                                                   # every context has captured its graph
+    if depth == 1:
+        proc = pipe.contexts[0]
+    else:                                                          # the per-kernel passes and the other measurements: one default (three-stream) context
+        proc = mp.MusicaProcessing(device=local_rank)
+        if not proc.init(n, levels=levels, batch=batch, flags=flags):
+            raise SystemExit("musica_create failed: " + mp.last_error())
+        proc.upload(px)
+        for _ in range(2):
+            proc.execute_device()
+        proc.sync()
 
     d_stats = torch.zeros((batch, mb.STATS_WORDS), dtype=torch.int32, device="cuda")
-    d_ids = torch.tensor(image_ids, dtype=torch.int32, device="cuda")
 
     def barrier():
         if distributed:
             dist.barrier()
 
     def step():
+        try:
+            pipe.step()
+        except RuntimeError as e:
+            raise SystemExit(str(e))
+
+    def step_one():
         if not proc.execute_device():
             raise SystemExit("musica_execute_device failed: " + mp.last_error())
 
     def finish_job():
-        """End of a job: per-image stats rows on the device, job-wide image ids, one all-gather."""
-        proc.stats_device(d_stats.data_ptr(), image_id_base=0)
-        proc.sync()
-        d_stats[:, 0] = d_ids                                      # the job-wide image ids of this rank's shard
+        """End of a job: per-image stats rows of the last step on the device (image ids job-wide: rank + index * world,
+        batch.assign_images), every context drained, one all-gather."""
+        pipe.last().stats_device(d_stats.data_ptr(), image_id_base=rank, image_id_stride=world)
+        pipe.sync()
         return mb.gather_rows(d_stats, world, dist if distributed else None)   # RCCL over xGMI: the only inter-GPU traffic
 
     for _ in range(args.warmup):
         step()
     finish_job()                                                   # untimed rehearsal: loads torch's / RCCL's kernels, connects the ranks
-    proc.sync()
 
     # The timed region replays the captured hipGraph (the product's default dispatch). ROCm 7.2 stream capture
     # drops hipEventRecord calls (devtools/graph_events.hip), so HIP events around a kernel need eager launches:
@@ -220,10 +243,15 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter()
     gathered = finish_job()
+    t_fin = time.perf_counter()
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
+    if os.environ.get("MUSICA_BENCH_TRACE") == "1":
+        sys.stderr.write("timed region: %d steps enqueued after %.3f ms, finish_job returned after %.3f ms, end %.3f ms\n"
+                         % (args.steps, (t_enq - t0) * 1e3, (t_fin - t0) * 1e3, (t1 - t0) * 1e3))
 
     elapsed = t1 - t0
     if distributed:
@@ -237,6 +265,19 @@ def main():
 
     proc.profile_enable(False)
     prof_timed = proc.profile()
+    # the same K steps on ONE context (every step behind the previous one): reported beside `value`
+    if depth > 1:
+        for q in pipe.contexts[1:]:                                # keep one pipeline context for the record, free the others
+            q.cleanup()
+        pipe.contexts = pipe.contexts[:1]
+    step_one()
+    proc.sync()
+    ts0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_one()
+    proc.sync()
+    one_ctx_ms = (time.perf_counter() - ts0) / args.steps * 1e3
+    step = step_one
     prof = {}
     if not args.no_kernel_events:
         if not kernel_events:
@@ -394,19 +435,23 @@ def main():
             "metric": "megapixels/sec full MUSICA pipeline", "value": round(mpix / elapsed, 1), "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "image_size": n, "levels": levels, "images_per_gpu_per_step": batch,
+            "config": {"workload": desc, "image_size": n, "levels": levels, "images_per_gpu_per_step": batch, "contexts_in_flight": depth,
                        "input": "seeded phantoms, %d-bit" % bits, "dispatch": "eager launches" if (kernel_events or os.environ.get("MUSICA_GRAPH", "1") == "0") else "hipGraph replay",
                        "kernel_events_in_timed_region": kernel_events, "sharding": "image k -> rank k mod N, no data-path collective",
                        "stats_gathered": int(st.shape[0]), "ranks_joined": world},
             "parity": "bit-identical to the build's CPU oracle in the separable arithmetic order the kernels use; against the shaders' literal 25-tap "
                       "order within 4e-7 per stencil / 4e-6 after reconstruction (tests/test_gpu_parity.py); parity with the reference itself is unpinned",
             "roofline": roofline, "roofline_4096_warm": warm, "roofline_pipeline_l0": pipeline_l0, "cpu_baseline": cpu, "kernels": kernels,
+            "one_context": {"ms_per_step": round(one_ctx_ms, 4), "value": round(batch * n * n / 1e6 / (one_ctx_ms * 1e-3), 1), "unit": "MP/s per GPU",
+                            "what": "the same %d steps on one three-stream context, each step behind the previous one (rank 0)" % args.steps},
             "e2e_host_MPps": round(e2e, 1),
             "e2e_host_overlapped": {"value": round(e2e_stream, 1), "unit": "MP/s", "what": "musica_execute_stream over %d batches in pinned host memory: H2D of batch j+1 under the kernels of batch j (PCIe-inclusive; never `value`)" % reps,
                                     "pcie_bound_MPps": round(63e9 / 2 / 1e6, 1), "fraction_of_device_rate": round(e2e_stream / (mpix / elapsed), 3)},
             "single_image": single,
         }
-    proc.cleanup()
+    if depth > 1:
+        proc.cleanup()
+    pipe.cleanup()
     if distributed:
         dist.barrier()          # rank 0 measured the stand-alone kernel after the timed region: leave together
         dist.destroy_process_group()

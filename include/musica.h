@@ -99,6 +99,9 @@ typedef struct musica_stats {
 #define MUSICA_FLAG_CLAHE      0x1u /* CLAHE gradation (reference: #ifdef ENABLE_CLAHE, vk_processing.h:13) */
 #define MUSICA_FLAG_NO_GRAPH   0x2u /* launch kernels eagerly instead of replaying a captured hipGraph */
 #define MUSICA_FLAG_GENERIC_KERNELS 0x4u /* test hook: use the one-thread-per-texel kernels at every level */
+#define MUSICA_FLAG_LINEAR     0x10u /* one in-order stream in the reference's submission order (src/vk_processing.cpp:2104-2601) instead of the
+                                        three-stream form: for contexts that run beside other contexts on one GPU (each then owns one
+                                        stream = one hardware queue; 4 such contexts with alternating steps: +15 % throughput) */
 #define MUSICA_FLAG_NO_AUTOTUNE 0x8u /* skip the init-time launch-geometry autotune (rows per wavefront stay heuristic) */
 
 /* Construction parameters: the reference hard-wires these as literals
@@ -225,6 +228,9 @@ int musica_get_stats(musica_ctx* ctx, uint32_t image_index, musica_stats* dst);
  * image_id = image_id_base + index) into caller-owned DEVICE memory, asynchronously on the ctx
  * stream: the buffer the multi-GPU batch driver hands to its RCCL all-gather. */
 int musica_stats_device(musica_ctx* ctx, void* d_dst, uint32_t image_id_base);
+/* The same with image_id = image_id_base + index * image_id_stride: a rank of the batch driver owns the images
+ * rank, rank + world, rank + 2 * world, ..., so its rows carry their job-wide ids without a second kernel. */
+int musica_stats_device_strided(musica_ctx* ctx, void* d_dst, uint32_t image_id_base, uint32_t image_id_stride);
 /* CLAHE state (only with MUSICA_FLAG_CLAHE): 4*4*256 u32 histograms [tx][ty][bin], 4*4*256 curve points. */
 int musica_get_clahe_hist(musica_ctx* ctx, uint32_t image_index, uint32_t* dst);
 int musica_get_clahe_curves(musica_ctx* ctx, uint32_t image_index, musica_point* dst);

@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-from .processing import Stats
+from .processing import FLAG_LINEAR, MusicaProcessing, Stats, last_error
 
 STATS_WORDS = C.sizeof(Stats) // 4  # 17 x 32-bit words per image
 
@@ -79,3 +79,72 @@ def process_shard(proc, images, image_ids):
             st.image_id = image_ids[start + k]
             rows[start + k] = stats_to_row(st)
     return rows
+
+
+class ShardPipeline:
+    """`depth` contexts of ONE GPU whose steps alternate: step s is enqueued on context s mod depth.
+
+    A step is a chain of dependent launches: chip-filling kernels at level 0, then small-level kernels, curve kernels and
+    the gaps between dependent launches, during which a lone context leaves most of the GPU idle (~a sixth of a step).
+    Contexts in flight fill each other's bubbles. Each context here is created with MUSICA_FLAG_LINEAR: ONE in-order
+    stream, so consecutive contexts land on different hardware queues (the runtime has 4) and no step waits for an
+    event of another queue. 8 x 2048^2 / L6 on MI355X: one three-stream context 0.484 ms per step, one linear context 0.50,
+    two / three / four / six linear contexts in flight 0.41 / 0.375 / 0.405 / 0.375 ms (DESIGN.md, "Steps in flight";
+    one 2048^2 image per step: 0.213 -> 0.093 ms; more than 4 hardware queues are worse).
+    Every context owns its buffers, stream and captured graph; a step's results are bit-identical to a lone
+    context's (tests/test_gpu_parity.py). The reference has one VulkanProcessing per process and one frame in flight
+    (src/vk_processing.cpp:2104-2601); this is the batch driver's throughput form of it.
+    """
+
+    def __init__(self, image_size, levels=0, batch=1, depth=3, flags=0, device=0):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.contexts = []
+        if depth > 1:
+            flags |= FLAG_LINEAR
+        for _ in range(depth):
+            p = MusicaProcessing(device=device)
+            if not p.init(image_size, levels=levels, batch=batch, flags=flags):
+                self.cleanup()
+                raise RuntimeError("musica_create failed: " + last_error())
+            self.contexts.append(p)
+        self.depth = depth
+        self.batch = batch
+        self.steps = 0
+
+    def upload(self, images):
+        """The shard resident in every context's input buffer (one array for all, or one per context)."""
+        per_ctx = isinstance(images, (list, tuple))
+        if per_ctx and len(images) != self.depth:
+            raise ValueError("need one image batch per context")
+        for k, p in enumerate(self.contexts):
+            p.upload(images[k] if per_ctx else images)
+
+    def prime(self):
+        """Two untimed steps per context (the first captures its graph, the second replays it), then drain."""
+        for _ in range(2):
+            for p in self.contexts:
+                if not p.execute_device():
+                    raise RuntimeError("musica_execute_device failed: " + last_error())
+        self.sync()
+
+    def step(self, d_pixels=None):
+        """Enqueue one step (asynchronous) on the next context; returns that context."""
+        p = self.contexts[self.steps % self.depth]
+        if not p.execute_device(d_pixels):
+            raise RuntimeError("musica_execute_device failed: " + last_error())
+        self.steps += 1
+        return p
+
+    def last(self):
+        """The context that ran the most recent step."""
+        return self.contexts[(self.steps - 1) % self.depth]
+
+    def sync(self):
+        for p in self.contexts:
+            p.sync()
+
+    def cleanup(self):
+        for p in self.contexts:
+            p.cleanup()
+        self.contexts = []

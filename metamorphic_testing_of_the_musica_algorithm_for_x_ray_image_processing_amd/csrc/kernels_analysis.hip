@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void k_stats(const float* __restrict__ cnr, in
                                                const uint32_t* __restrict__ minmax, int min_chain_exact,
                                                const musica_hist_max_point* __restrict__ noise_max, int levels,
                                                const musica_hist_max_point* __restrict__ grad_max, const DevCurve* __restrict__ gcurve,
-                                               musica_stats* __restrict__ out, uint32_t image_id_base) {
+                                               musica_stats* __restrict__ out, uint32_t image_id_base, uint32_t image_id_stride) {
     __shared__ double part[256];
     const int img = blockIdx.x;
     const float* p = cnr + (size_t)img * plane;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void k_stats(const float* __restrict__ cnr, in
     }
     if (threadIdx.x != 0) return;
     musica_stats st;
-    st.image_id = image_id_base + (uint32_t)img;
+    st.image_id = image_id_base + (uint32_t)img * image_id_stride;
     chain_scalars(minmax, img, min_chain_exact, st.min_sqrt, st.max_sqrt);
     for (int l = 0; l < 4; l++) {
         const musica_hist_max_point mp = noise_max[(size_t)img * levels + l];
@@ -569,9 +569,9 @@ void launch_selftest_exact_math(hipStream_t st, unsigned long long* d_bad4) {
 
 void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact,
                   const musica_hist_max_point* noise_max, int levels, const musica_hist_max_point* grad_max, const DevCurve* gcurve,
-                  musica_stats* out, uint32_t image_id_base, int batch) {
+                  musica_stats* out, uint32_t image_id_base, uint32_t image_id_stride, int batch) {
     hipLaunchKernelGGL(k_stats, dim3(batch), dim3(256), 0, st, cnr, l3.S, l3.pitch, l3.plane, minmax, min_chain_exact, noise_max, levels,
-                       grad_max, gcurve, out, image_id_base);
+                       grad_max, gcurve, out, image_id_base, image_id_stride);
 }
 
 }  // namespace musica

@@ -31,6 +31,8 @@ __device__ v4f llvm_buffer_load_v4f32(v4i rsrc, int voffset, int soffset, int au
 __device__ v2f llvm_buffer_load_v2f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
 __device__ float llvm_buffer_load_f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ void llvm_buffer_store_v4f32(v4f data, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+__device__ short llvm_buffer_load_i16(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i16");
+__device__ void llvm_buffer_store_i16(short data, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i16");
 constexpr uint32_t kOob = 0x80000000u;
 
 struct Buf {
@@ -61,6 +63,8 @@ __device__ __forceinline__ float2 bload2(const Buf& b, uint32_t off) {
     return make_float2(v.x, v.y);
 }
 __device__ __forceinline__ float bload1(const Buf& b, uint32_t off) { return llvm_buffer_load_f32(b.r, (int)off, 0, 0); }
+__device__ __forceinline__ uint32_t bload_u16(const Buf& b, uint32_t off) { return (uint32_t)(uint16_t)llvm_buffer_load_i16(b.r, (int)off, 0, 0); }
+__device__ __forceinline__ void bstore_u16(const Buf& b, uint32_t off, uint32_t v) { llvm_buffer_store_i16((short)v, b.r, (int)off, 0, 0); }
 __device__ __forceinline__ void bstore4(const Buf& b, uint32_t off, float4 v) {
     v4f u;
     u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;

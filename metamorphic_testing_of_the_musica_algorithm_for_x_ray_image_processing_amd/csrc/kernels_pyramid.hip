@@ -491,6 +491,17 @@ __device__ __forceinline__ void band_pair(const CRow& a, const CRow& b, const CR
     store8(bb, g.off + off_o, bo);
 }
 
+// bit j: fe.v[j] <= 0.9, bit 8 + j: fo.v[j] <= 0.9 — the shader's own comparison on the normalized value (NaN: false)
+__device__ __forceinline__ uint32_t le090_bits(const FRow& fe, const FRow& fo) {
+    uint32_t m = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        m |= fe.v[j] <= 0.90f ? 1u << j : 0u;
+        m |= fo.v[j] <= 0.90f ? 1u << (8 + j) : 0u;
+    }
+    return m;
+}
+
 __device__ __forceinline__ void load_f(FRow& r, const Buf& b, uint32_t row_off, uint32_t off, uint32_t off_h) {
     load8(r.v, b, off + row_off);
     const float4 h = bload4(b, off_h + row_off);
@@ -502,9 +513,10 @@ __device__ __forceinline__ void load_f(FRow& r, const Buf& b, uint32_t row_off, 
 // raw pixels (6 registers) one trip ahead. Otherwise the fine image is f32 (levels >= 1): the rows are loaded where they are
 // needed (a prefetch would cost 24 registers and a wavefront per SIMD; these levels are small and L2-resident).
 template <bool U16>
-__global__ __launch_bounds__(kBlockThreads) void k_reduce_band(const void* __restrict__ fine, float* __restrict__ down, float* __restrict__ band,
+__global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __restrict__ fine, float* __restrict__ down, float* __restrict__ band,
                                                                int S, int pitch, size_t plane, int Sc, int cpitch, size_t cplane,
-                                                               int rows_per_wave, const uint32_t* __restrict__ minmax, int min_chain_exact) {
+                                                               int rows_per_wave, const uint32_t* __restrict__ minmax, int min_chain_exact,
+                                                               uint16_t* __restrict__ le090) {
     const int lane = threadIdx.x & 63;
     const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
     const int k0 = seg * rows_per_wave;
@@ -522,6 +534,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_band(const void* __res
     const Buf db = make_buf(down + (size_t)img * cplane, cplane * 4);
     const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
     const LaneCfg g = make_cfg(blockIdx.x, lane, S);
+    // U16 with le090: one uint16 per lane and row pair, bit j / 8 + j = `normalized <= 0.9` (img_relevant.comp:58) of column c + j in the
+    // even / odd row — the level-0 expand launch bins the gradation histogram with it instead of reading the raw pixels again
+    const bool want_mask = U16 && le090 != nullptr;
+    const Buf mb = want_mask ? make_buf(le090 + (size_t)img * Sc * (S / 8), (size_t)Sc * (S / 8) * 2) : bb;
+    const uint32_t moff = g.off == kOob ? kOob : (uint32_t)g.c >> 2, mrb = (uint32_t)S >> 2;
     // own pixels and four halo pixels: c-4 .. c-1 (lane 0 of a strip that is not the first) or c+8 .. c+11 (lane 63 with more image to its right)
     const uint32_t px_bytes = U16 ? 2u : 4u;
     const uint32_t foff = g.off == kOob ? kOob : (uint32_t)g.c * px_bytes;
@@ -565,14 +582,18 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_band(const void* __res
         // coarse row k completes the neighbourhood of row k-1: band rows 2(k-1), 2(k-1)+1 are the two oldest rows of the window.
         // km1(0) = coarse_of_fine(-2) = 1 (reflect-101 on the fine grid, img_smooth_upsampled.comp:10-16): row k itself.
         const int kp = k - 1;
-        if (kp >= k0 && kp < k1)  // wave-uniform
+        if (kp >= k0 && kp < k1) {  // wave-uniform
+            if (want_mask) bstore_u16(mb, moff + (uint32_t)kp * mrb, le090_bits(w0, w1));
             band_pair(kp == 0 ? c0 : cm2, cm1, c0, w0, w1, g, bb, (uint32_t)(2 * kp) * rb, (uint32_t)(2 * kp + 1) * rb);
+        }
         cm2 = cm1; cm1 = c0;
         w0 = w2; w1 = w3; w2 = w4;
     }
     // the last row pair of the image: kp1(Sc-1) = coarse_of_fine(S) = Sc-1 (fine row S mirrors onto S-2)
-    if (k1 == Sc)
+    if (k1 == Sc) {
+        if (want_mask) bstore_u16(mb, moff + (uint32_t)(Sc - 1) * mrb, le090_bits(w0, w1));
         band_pair(cm2, cm1, cm1, w0, w1, g, bb, (uint32_t)(2 * (Sc - 1)) * rb, (uint32_t)(2 * (Sc - 1) + 1) * rb);
+    }
 }
 
 // lowpass value at fine (x, y) for any S (generic form).
@@ -685,7 +706,9 @@ __device__ __forceinline__ float curve_eval_lut(const CurveLds& t, const LutLds&
 // kernel (k_grad_hist) then recounts that image into a second histogram and k_grad_curve takes that one. The relevance
 // weight uint(relevant * 100) is the one k_grad_hist computes: one cnr classification per lane and row pair (the cnr scale
 // is 8 here, so a lane's 8 columns and both rows of a pair sit under one cnr texel), `normalized <= 0.9` on the raw pixel.
-template <int GAIN, bool NR, int T, bool GH, int W = 1>
+// MASK: `normalized <= 0.9` comes as the bit image k_reduce_band<true> wrote (2 bytes per lane and row pair) instead of raw pixels
+// against thr090 (32 bytes).
+template <int GAIN, bool NR, int T, bool GH, int W = 1, bool MASK = false>
 __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) {
     __shared__ CurveLds tab;
     __shared__ __attribute__((aligned(16))) LutLds lut;
@@ -719,10 +742,11 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
     const Buf sb = make_buf((GAIN != GAIN_CONST ? a.sdev : a.band) + (size_t)img * a.plane, a.plane * 4);
     const Buf ob = make_buf(a.recon + (size_t)img * a.plane, a.plane * 4);
     const Buf pb = make_buf(a.prev + (size_t)img * a.cplane, a.cplane * 4);
-    const Buf wb = GH ? make_buf(a.raw + (size_t)img * S * S, (size_t)S * S * 2) : bb;
+    const Buf wb = !GH ? bb : MASK ? make_buf(a.le090 + (size_t)img * a.Sc * (S / 8), (size_t)a.Sc * (S / 8) * 2) : make_buf(a.raw + (size_t)img * S * S, (size_t)S * S * 2);
     const float* cnr = NR ? a.cnr + (size_t)img * a.cnrPlane : nullptr;
     const LaneCfg g = make_cfg(blockIdx.x, lane, S);
     const uint32_t rb = (uint32_t)a.pitch * 4u, crb = (uint32_t)a.cpitch * 4u;
+    const uint32_t moff = g.off == kOob ? kOob : (uint32_t)g.c >> 2, mrb = (uint32_t)S >> 2;
     const uint32_t urb = (uint32_t)S * 2u, uoff = g.off == kOob ? kOob : g.off >> 1;
     // noise reduction: the 8 columns of a lane share ceil(8 / scale) cnr texels per row
     const int cxs[2] = {g.active ? g.c / a.cnrScale : 0, g.active ? (g.c + 4) / a.cnrScale : 0};
@@ -734,7 +758,7 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
         for (int j = 0; j < 8; j++)
             if (g.active && (uint32_t)(g.c + j) > border && (uint32_t)(g.c + j) < lim) colin |= 1u << j;
     }
-    const int thr = GH ? a.thr090[img] : 0;
+    const int thr = GH && !MASK ? a.thr090[img] : 0;
     uint32_t* lhc = lh + (GH ? (lane & (kGhCopies - 1)) * kGhStride : 0);
 
     CRow cw[T + 2];
@@ -743,6 +767,7 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
     for (int k = k0; k < k1; k += T) {
         float be[T][8], bo[T][8], se[T][8], so[T][8];
         float4 we[T], wo[T];   // raw uint16 rows (GH)
+        uint32_t le[T];        // or their `<= 0.9` bits (GH, MASK)
 #pragma unroll
         for (int t = 0; t < T; t++) {
             const int ka = min(k + t, k1 - 1);
@@ -753,7 +778,8 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
                 load8(se[t], sb, g.off + (uint32_t)(2 * ka) * rb);
                 load8(so[t], sb, g.off + (uint32_t)(2 * ka + 1) * rb);
             }
-            if (GH) {
+            if (GH && MASK) le[t] = bload_u16(wb, moff + (uint32_t)ka * mrb);
+            else if (GH) {
                 we[t] = bload4(wb, uoff + (uint32_t)(2 * ka) * urb);
                 wo[t] = bload4(wb, uoff + (uint32_t)(2 * ka + 1) * urb);
             }
@@ -803,8 +829,9 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
                     }
                     store8(ob, g.off + (uint32_t)(2 * kk + ph) * rb, b);
                     if (GH) {
-                        const float4 wr = ph ? wo[t] : we[t];
+                        const float4 wr = MASK ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ph ? wo[t] : we[t];
                         const uint32_t raw[4] = {__float_as_uint(wr.x), __float_as_uint(wr.y), __float_as_uint(wr.z), __float_as_uint(wr.w)};
+                        const uint32_t dark = MASK ? le[t] >> (8 * ph) : 0u;
                         const uint32_t y = (uint32_t)(2 * kk + ph);
                         const uint32_t m = (y > border && y < lim) ? colin : 0u;   // inside-the-border bits of the lane's 8 columns in this row
 #pragma unroll
@@ -817,7 +844,8 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
                             // (-1, 0) truncates to bin 0 like the shader's int(); everything out of range lands on the spare word 1024
                             const uint32_t bin = min((uint32_t)(int)fminf(fmaxf(cur * (float)MUSICA_GRAD_BINS, -1.0f), 2048.0f), (uint32_t)MUSICA_GRAD_BINS);
                             // :28-30 uint(relevant * 100): 0 outside the border; adding 0 leaves the histogram as it is
-                            const uint32_t w = ((m >> j) & 1u) * (px <= thr ? w_dark_or_ramp : w_cnr);
+                            const bool le090 = MASK ? ((dark >> j) & 1u) != 0u : px <= thr;
+                            const uint32_t w = ((m >> j) & 1u) * (le090 ? w_dark_or_ramp : w_cnr);
                             atomicAdd(&lhc[bin], w);
                         }
                     }
@@ -927,14 +955,14 @@ void launch_reduce_u16(hipStream_t st, const uint16_t* px, const LevelDesc& li, 
                        lo.plane, rows_per_wave, minmax, min_chain_exact);
 }
 void launch_reduce_band_u16(hipStream_t st, const uint16_t* px, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
-                            int rows_per_wave, const uint32_t* minmax, int min_chain_exact) {
+                            int rows_per_wave, const uint32_t* minmax, int min_chain_exact, uint16_t* le090) {
     hipLaunchKernelGGL(k_reduce_band<true>, stream_grid(lf.S, lc.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, (const void*)px, down, band, lf.S,
-                       lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
+                       lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact, le090);
 }
 // levels >= 1 (f32 fine image); the side must be a multiple of 8 and at least 16 (the caller checks)
 void launch_reduce_band(hipStream_t st, const float* fine, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave) {
     hipLaunchKernelGGL(k_reduce_band<false>, stream_grid(lf.S, lc.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, (const void*)fine, down, band, lf.S,
-                       lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, (const uint32_t*)nullptr, 0);
+                       lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, (const uint32_t*)nullptr, 0, (uint16_t*)nullptr);
 }
 void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                      int rows_per_wave, int rows_per_trip, const uint32_t* minmax, int min_chain_exact) {
@@ -972,7 +1000,9 @@ static void launch_expand_t(hipStream_t st, const ExpandArgs& a, int batch, bool
         if (GAIN == GAIN_CURVE && NR && a.ghist) {   // level 0 with the gradation histogram on board (the caller checked cnrScale == 8)
             // W = 4: register allocation capped at 128 (4 wavefronts per SIMD, 16 dwords of scratch) against 143 registers and 3 wavefronts
             static const int occ = getenv("MUSICA_GH_OCC") ? atoi(getenv("MUSICA_GH_OCC")) : 4;
-            if (rows_per_trip >= 2) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 2, true>), grid, dim3(kBlockThreads), 0, st, a);
+            if (a.le090 && rows_per_trip < 2 && occ >= 4) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 4, true>), grid, dim3(kBlockThreads), 0, st, a);
+            else if (a.le090) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 1, true>), grid, dim3(kBlockThreads), 0, st, a);
+            else if (rows_per_trip >= 2) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 2, true>), grid, dim3(kBlockThreads), 0, st, a);
             else if (occ >= 4) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 4>), grid, dim3(kBlockThreads), 0, st, a);
             else hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 1>), grid, dim3(kBlockThreads), 0, st, a);
         }

@@ -38,6 +38,7 @@ struct ExpandArgs {
     uint32_t* ghist;         // [batch][1024]
     uint32_t* gzero;         // [batch]: set when a reconstructed texel is exactly 0 (the `return` of gradation_histogram.comp:24
                              // then cuts the scan of its 16 x 16 area short: k_grad_hist redoes that image literally)
+    const uint16_t* le090;   // or: [batch][Sc][S / 8] bits of `normalized <= 0.9` written by launch_reduce_band_u16 (then raw / thr090 are not read)
     const int* thr090;       // [batch]: largest raw value whose normalized value is <= 0.9 (k_curves_cnr)
 };
 
@@ -62,7 +63,7 @@ void launch_band(hipStream_t st, const float* fine, const float* coarse, float* 
 void launch_reduce_u16(hipStream_t st, const uint16_t* px, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave,
                        const uint32_t* minmax, int min_chain_exact);
 void launch_reduce_band_u16(hipStream_t st, const uint16_t* px, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
-                            int rows_per_wave, const uint32_t* minmax, int min_chain_exact);
+                            int rows_per_wave, const uint32_t* minmax, int min_chain_exact, uint16_t* le090);
 void launch_reduce_band(hipStream_t st, const float* fine, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave);
 void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                      int rows_per_wave, int rows_per_trip, const uint32_t* minmax, int min_chain_exact);
@@ -84,7 +85,7 @@ void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& 
 void launch_selftest_exact_math(hipStream_t st, unsigned long long* d_bad4);
 void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact,
                   const musica_hist_max_point* noise_max, int levels, const musica_hist_max_point* grad_max, const DevCurve* gcurve,
-                  musica_stats* out, uint32_t image_id_base, int batch);
+                  musica_stats* out, uint32_t image_id_base, uint32_t image_id_stride, int batch);
 // kernels_gradation.hip
 void launch_grad_hist(hipStream_t st, const GradArgs& a, int batch);
 void launch_grad_hist_ref(hipStream_t st, const float* img, const float* relevant, const LevelDesc& l0, uint32_t* hist, int batch);

@@ -98,6 +98,7 @@ struct musica_ctx {
     uint32_t* d_grad_hist_b;   // the literal recount of images whose reconstruction holds an exact zero (fused gradation histogram)
     uint32_t* d_gzero;         // [B]: that condition
     int* d_thr090;             // [B]: raw-pixel form of `normalized <= 0.9`
+    uint16_t* d_le090;         // [B][S1][S0 / 8] or null: its bit image, written by the level-0 reduce + band launch for the level-0 expand launch
     bool fuse_gh;              // the level-0 expand launch accumulates the gradation histogram
     int fuse_rb;               // smooth + downsample and the band-pass image of a level in one launch (k_reduce_band): 0 off, 1 level 0 only,
                                // 2 every level whose side is a multiple of 8
@@ -250,6 +251,7 @@ static musica_ctx* make_view(const musica_ctx* c, int i0, int nb) {
     v->d_grad_hist_b += o * MUSICA_GRAD_BINS;
     v->d_gzero += o;
     v->d_thr090 += o;
+    if (v->d_le090) v->d_le090 += o * (size_t)c->lv[1].S * (c->lv[0].S / 8);
     v->d_grad_max += o;
     v->d_gcurve += o;
     v->d_graded += o * c->lv[0].plane;
@@ -405,19 +407,23 @@ static musica_ctx* create_impl(const musica_params* params) {
     if (c->grad_groups < 1) c->grad_groups = 1;
 
     const size_t B = (size_t)c->B;
-    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->side1, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->ev_s1, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->ev_s2, hipEventDisableTiming) == hipSuccess;
-    // 1: the three-stream form (enqueue_dag); 0: one in-order stream, the reference's order. (A one-stream-per-level form was the
-    // default for single images in round 1; the three-stream form with its present ordering is faster for every workload
-    // measured: one 2048^2 image 0.204 vs 0.215 ms, 4096^2 + CLAHE 0.609 vs 0.633 ms.)
-    c->dag = env_int("MUSICA_DAG", 1);
+    // 1: the three-stream form (enqueue_dag), the fastest for a context that has the GPU to itself (one 2048^2 image 0.204 vs
+    // 0.215 ms, 8 x 2048^2 0.484 vs 0.496 ms); 0 (MUSICA_FLAG_LINEAR, or MUSICA_DAG=0): one in-order stream in the reference's
+    // order — the form for contexts whose steps run beside other contexts' steps (batch.ShardPipeline): such a context
+    // creates ONE stream, so that the runtime's round-robin puts consecutive contexts on different hardware queues
+    // (4 by default), and nothing of a step ever waits for an event of another queue. Both forms replay a captured hipGraph.
+    c->dag = (params->flags & MUSICA_FLAG_LINEAR) ? 0 : env_int("MUSICA_DAG", 1);
     if (c->dag < 0 || c->dag > 1) c->dag = 1;
-    c->use_graph = c->dag && !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", 1) != 0;
+    c->use_graph = !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", 1) != 0;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    if (c->dag) {
+        ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&c->side1, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->ev_s1, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->ev_s2, hipEventDisableTiming) == hipSuccess;
+    }
     c->graph_exec[0] = c->graph_exec[1] = nullptr;
     c->graph_input[0] = c->graph_input[1] = nullptr;
     c->graph_next = 0;
@@ -448,6 +454,8 @@ static musica_ctx* create_impl(const musica_params* params) {
     ok = ok && dalloc(c, &c->d_grad_hist_b, B * MUSICA_GRAD_BINS);
     ok = ok && dalloc(c, &c->d_gzero, B);
     ok = ok && dalloc(c, &c->d_thr090, B);
+    c->d_le090 = nullptr;
+    if (c->fuse_gh && c->fuse_rb >= 1 && env_int("MUSICA_LE090", 1) != 0) ok = ok && dalloc(c, &c->d_le090, B * (size_t)c->lv[1].S * (c->lv[0].S / 8));
     ok = ok && dalloc(c, &c->d_grad_max, B);
     ok = ok && dalloc(c, &c->d_gcurve, B);
     ok = ok && dalloc(c, &c->d_graded, B * c->lv[0].plane);
@@ -473,7 +481,7 @@ static musica_ctx* create_impl(const musica_params* params) {
         c->rows_band[i] = pick_rows(c->band_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
         c->rows_expand[i] = pick_rows(c->expand_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
         if (i <= MUSICA_CNR_LEVEL) c->rows_sdev[i] = pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, c->B);
-        c->rows_rb[i] = pick_rows(16, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
+        c->rows_rb[i] = pick_rows(env_int("MUSICA_RB_ROWS", 16), 1, c->lv[i].S, c->lv[i + 1].S, c->B);
     }
     const bool tune = !(params->flags & MUSICA_FLAG_NO_AUTOTUNE) && env_int("MUSICA_AUTOTUNE", 1) && !c->generic;
     const int groups = pick_groups(c);
@@ -580,7 +588,7 @@ static bool rb_level(const musica_ctx* c, int i) {
 }
 static void run_reduce_band(musica_ctx* c, int i, int rows) {
     if (i == 0 && c->fuse_u16)
-        launch_reduce_band_u16(c->cur, c->cur_input, c->d_down[0], c->d_band[0], c->lv[0], c->lv[1], c->B, rows, c->d_minmax, c->min_chain_exact);
+        launch_reduce_band_u16(c->cur, c->cur_input, c->d_down[0], c->d_band[0], c->lv[0], c->lv[1], c->B, rows, c->d_minmax, c->min_chain_exact, c->d_le090);
     else
         launch_reduce_band(c->cur, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, rows);
 }
@@ -645,7 +653,7 @@ static ExpandArgs expand_args(musica_ctx* c, int lvl, float* dst) {
     const musica_nr_params& q = c->h_nr[lvl < 3 ? lvl : 0];
     a.lowCnr = q.lowCnr; a.lowFactor = q.lowFactor; a.highCnr = q.highCnr; a.highFactor = q.highFactor;
     a.rows_per_wave = c->rows_expand[lvl];
-    a.raw = nullptr; a.ghist = nullptr; a.gzero = nullptr; a.thr090 = nullptr;
+    a.raw = nullptr; a.ghist = nullptr; a.gzero = nullptr; a.thr090 = nullptr; a.le090 = nullptr;
     return a;
 }
 static int gain_mode(int lvl) { return lvl > MUSICA_CNR_LEVEL ? GAIN_CONST : (lvl == MUSICA_CNR_LEVEL ? GAIN_RANGE : GAIN_CURVE); }
@@ -657,6 +665,7 @@ static void run_expand_level_h(musica_ctx* c, int lvl, int rows, bool with_hist)
     a.rows_per_wave = rows;
     if (with_hist && lvl == 0 && c->fuse_gh && !c->generic) {
         a.raw = c->cur_input; a.ghist = c->d_grad_hist; a.gzero = c->d_gzero; a.thr090 = c->d_thr090;
+        a.le090 = c->d_le090;
     }
     launch_expand(c->cur, a, gain_mode(lvl), uses_nr(lvl), c->B, c->generic, c->expand_trip);
 }
@@ -774,7 +783,20 @@ static void enqueue_dag(musica_ctx* c) {
     enqueue_gradation(c, true);
 }
 
-static void enqueue_dag_any(musica_ctx* c) { enqueue_dag(c); }
+// One in-order stream, the order of the reference's command buffer (dag == 0).
+static void enqueue_linear(musica_ctx* c) {
+    c->cur = c->stream;
+    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B, c->d_grad_hist_b, c->d_gzero);  // :2153-2162
+    enqueue_norm(c);
+    enqueue_reduce(c);
+    enqueue_analysis(c);
+    enqueue_expand(c, true);
+    enqueue_gradation(c, true);
+}
+static void enqueue_script(musica_ctx* c) {
+    if (c->dag) enqueue_dag(c);
+    else enqueue_linear(c);
+}
 
 // Captures enqueue_dag() (both streams: the side stream joins the capture through ev_fork and rejoins
 // through ev_join) into an executable graph for the current input pointer.
@@ -783,7 +805,7 @@ static bool capture_graph(musica_ctx* c) {
     if (c->graph_exec[k]) { hipGraphExecDestroy(c->graph_exec[k]); c->graph_exec[k] = nullptr; c->graph_input[k] = nullptr; }
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
-    enqueue_dag_any(c);
+    enqueue_script(c);
     if (hipStreamEndCapture(c->stream, &graph) != hipSuccess || !graph) { (void)hipGetLastError(); return false; }
     const hipError_t e = hipGraphInstantiate(&c->graph_exec[k], graph, nullptr, nullptr, 0);
     hipGraphDestroy(graph);
@@ -820,7 +842,7 @@ static int enqueue_groups(musica_ctx* c) {
 
 static int enqueue_all(musica_ctx* c) {
     if (!c->views.empty() && !c->tuning) return enqueue_groups(c);
-    if (c->dag && !c->tuning && c->use_graph && c->profiling == 0) {
+    if (!c->tuning && c->use_graph && c->profiling == 0) {
         int k = (c->graph_exec[0] && c->graph_input[0] == c->cur_input) ? 0 : (c->graph_exec[1] && c->graph_input[1] == c->cur_input) ? 1 : -1;
         if (k < 0) {
             if (!capture_graph(c)) c->use_graph = false;   // e.g. a runtime without capture support: stay eager
@@ -833,19 +855,8 @@ static int enqueue_all(musica_ctx* c) {
             return 1;
         }
     }
-    if (c->dag && !c->tuning) {
-        enqueue_dag_any(c);
-        hipError_t e0 = hipGetLastError();
-        if (e0 != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e0));
-        return 1;
-    }
-    c->cur = c->stream;
-    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B, c->d_grad_hist_b, c->d_gzero);  // :2153-2162
-    enqueue_norm(c);
-    enqueue_reduce(c);
-    enqueue_analysis(c);
-    enqueue_expand(c, true);
-    enqueue_gradation(c, true);
+    if (c->tuning) enqueue_linear(c);
+    else enqueue_script(c);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e));
     return 1;
@@ -1021,7 +1032,7 @@ int musica_execute_stream(musica_ctx* c, const uint16_t* const* pixels, uint32_t
         ok = enqueue_all(c);
         if (ok && stats) {
             launch_stats(c->stream, c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_noise_max, c->L, c->d_grad_max, c->d_gcurve,
-                         d_rows + (size_t)j * c->B, j * (uint32_t)c->B, c->B);
+                         d_rows + (size_t)j * c->B, j * (uint32_t)c->B, 1u, c->B);
         }
         hipEventRecord(c->ev_consumed[k], c->stream);
     }
@@ -1258,15 +1269,16 @@ int musica_get_minmax(musica_ctx* c, uint32_t idx, float* min_sqrt, float* max_s
     *min_sqrt = c->min_chain_exact ? (float)(uint32_t)mn : 0.0f;
     return 1;
 }
-int musica_stats_device(musica_ctx* c, void* d_dst, uint32_t image_id_base) {
+int musica_stats_device_strided(musica_ctx* c, void* d_dst, uint32_t image_id_base, uint32_t image_id_stride) {
     CHECK_CTX(c);
     if (!d_dst) return fail("musica_stats_device: d_dst is NULL");
     launch_stats(c->stream, c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_noise_max, c->L, c->d_grad_max,
-                 c->d_gcurve, (musica_stats*)d_dst, image_id_base, c->B);
+                 c->d_gcurve, (musica_stats*)d_dst, image_id_base, image_id_stride, c->B);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e));
     return 1;
 }
+int musica_stats_device(musica_ctx* c, void* d_dst, uint32_t image_id_base) { return musica_stats_device_strided(c, d_dst, image_id_base, 1u); }
 int musica_get_stats(musica_ctx* c, uint32_t idx, musica_stats* dst) {
     CHECK_CTX(c); CHECK_IMG(c, idx);
     if (!musica_stats_device(c, c->d_stats, 0)) return 0;

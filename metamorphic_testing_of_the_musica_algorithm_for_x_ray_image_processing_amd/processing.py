@@ -27,6 +27,8 @@ OUT_MARGIN = 10
 FLAG_CLAHE = 0x1
 FLAG_NO_GRAPH = 0x2
 FLAG_GENERIC_KERNELS = 0x4
+FLAG_NO_AUTOTUNE = 0x8
+FLAG_LINEAR = 0x10
 
 IMG_NORMALIZED, IMG_DOWNSAMPLED, IMG_BANDPASS, IMG_SDEV, IMG_CNR, IMG_EXPAND = 0, 1, 2, 3, 4, 5
 IMG_GRADED, IMG_RELEVANT, IMG_LOWPASS, IMG_EXP_BANDPASS, IMG_SQRT, IMG_CLAHE_GRADED, IMG_CONTRAST_BAND = 6, 7, 8, 9, 10, 11, 12
@@ -124,6 +126,7 @@ ABI = {
     "musica_get_minmax": (C.c_int, [_VP, C.c_uint32, _F32P, _F32P]),
     "musica_get_stats": (C.c_int, [_VP, C.c_uint32, C.POINTER(Stats)]),
     "musica_stats_device": (C.c_int, [_VP, _VP, C.c_uint32]),
+    "musica_stats_device_strided": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32]),
     "musica_get_clahe_hist": (C.c_int, [_VP, C.c_uint32, _U32P]),
     "musica_get_clahe_curves": (C.c_int, [_VP, C.c_uint32, C.POINTER(Point)]),
     "musica_debug_process": (C.c_int, [_VP, C.c_uint32, C.c_char_p]),
@@ -367,9 +370,10 @@ class MusicaProcessing:
         self._ok(self._lib.musica_get_stats(self._h, image_index, C.byref(s)), "musica_get_stats")
         return s
 
-    def stats_device(self, d_dst, image_id_base=0):
-        """Write batch x musica_stats into caller-owned device memory (async on the ctx stream)."""
-        self._ok(self._lib.musica_stats_device(self._h, d_dst, image_id_base), "musica_stats_device")
+    def stats_device(self, d_dst, image_id_base=0, image_id_stride=1):
+        """Write batch x musica_stats into caller-owned device memory (async on the ctx stream);
+        image_id = image_id_base + index * image_id_stride."""
+        self._ok(self._lib.musica_stats_device_strided(self._h, d_dst, image_id_base, image_id_stride), "musica_stats_device")
 
     def clahe_hist(self, image_index=0):
         out = np.empty((4, 4, 256), dtype=np.uint32)

@@ -185,7 +185,8 @@ def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
             p.cleanup()
 
 
-@pytest.mark.parametrize("env", [{"MUSICA_BAND_TRIP": "1"}, {"MUSICA_EXPAND_TRIP": "2"}, {"MUSICA_U16": "0"}, {"MUSICA_FUSE_GH": "0"}, {"MUSICA_GH_OCC": "3"}, {"MUSICA_FUSE_RB": "0"},
+@pytest.mark.parametrize("env", [{"MUSICA_BAND_TRIP": "1"}, {"MUSICA_EXPAND_TRIP": "2"}, {"MUSICA_U16": "0"}, {"MUSICA_FUSE_GH": "0"}, {"MUSICA_GH_OCC": "3"}, {"MUSICA_FUSE_RB": "0"}, {"MUSICA_FUSE_RB": "1"}, {"MUSICA_LE090": "0"}, {"MUSICA_GH_OCC": "3", "MUSICA_LE090": "1"},
+                                 {"MUSICA_FUSE_RB": "2", "MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "4"}, {"MUSICA_FUSE_RB": "2", "MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "64"},
                                  {"MUSICA_FUSE_GH": "1", "MUSICA_EXPAND_TRIP": "2"},
                                  {"MUSICA_AUTOTUNE": "0", "MUSICA_REDUCE_ROWS": "4", "MUSICA_BAND_ROWS": "2", "MUSICA_EXPAND_ROWS": "2", "MUSICA_SDEV_ROWS": "16"},
                                  {"MUSICA_AUTOTUNE": "0", "MUSICA_REDUCE_ROWS": "32", "MUSICA_BAND_ROWS": "16", "MUSICA_EXPAND_ROWS": "16", "MUSICA_SDEV_ROWS": "64", "MUSICA_MIN_WAVES": "1"}],
@@ -611,3 +612,31 @@ def test_cli_drop_in(ob, tmp_path):
     # wrong file size -> MAIN ERROR, exit code 1 (main.cpp:57-60)
     r = subprocess.run([mp.CLI_PATH, str(raw), str(out), "--size", "256"], capture_output=True, text=True)
     assert r.returncode == 1 and "MAIN ERROR: the image data don't match the actual image size" in r.stderr
+
+
+def test_steps_in_flight_on_three_contexts_are_the_lone_contexts_steps(ob):
+    """batch.ShardPipeline: steps alternate over three linear contexts without waiting for one another (what bench.py times).
+    Each context holds DIFFERENT images, so a result that leaked between contexts would show; every image of every
+    context is bit-identical to the oracle after 7 overlapping steps, and the strided image ids of a rank's stats
+    rows (rank + index * world) come from the stats kernel itself."""
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd import batch as mb
+    n, levels, b, depth = 520, 5, 2, 3
+    px = [np.stack([phantom(n, 1000 + 10 * c + k) for k in range(b)]) for c in range(depth)]
+    pipe = mb.ShardPipeline(n, levels=levels, batch=b, depth=depth)
+    pipe.upload(px)
+    pipe.prime()
+    for _ in range(7):
+        pipe.step()
+    assert pipe.last() is pipe.contexts[0] and pipe.steps == 7
+    d_rows = pipe.last().device_alloc(b * mb.STATS_WORDS * 4)
+    pipe.last().stats_device(d_rows, image_id_base=3, image_id_stride=8)
+    pipe.sync()
+    rows = np.zeros((b, mb.STATS_WORDS), dtype=np.int32)
+    pipe.last().d2h(rows, d_rows)
+    assert [int(r[0]) for r in rows] == [3, 11]
+    pipe.last().device_free(d_rows)
+    for c in range(depth):
+        for k in range(b):
+            o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[c][k])
+            _compare_all(pipe.contexts[c], o, ob, idx=k, tag="context %d image %d: " % (c, k))
+    pipe.cleanup()
