@@ -55,28 +55,34 @@ COLD_BUFFERS = 8          # 8 x (64 MB in + 16 MB out) = 640 MB rotating footpri
 COLD_ITERS = 64
 
 
-def algorithmic_bytes(n, levels, batch, fused_u16=True, fused_gradhist=False, fused_rb=False):
+def algorithmic_bytes(n, levels, batch, fused_u16=True, fused_gradhist=False, fused_rb=0, le090=False):
     """Algorithmic HBM bytes per launch of each kernel family, f32 = 4 B, u16 = 2 B.
-    fused_u16: the level-0 kernels read the raw uint16 pixels (2 B/px) instead of a stored normalized image (4 B/px)."""
+    fused_u16: the level-0 kernels read the raw uint16 pixels (2 B/px) instead of a stored normalized image (4 B/px);
+    fused_rb: 1 = reduce + band of level 0 are one launch, 2 = of every level whose side is a multiple of 8 (then the
+    `reduce_*` families carry the band image too and no `band_*` launch remains at those levels);
+    le090: the level-0 reduce + band launch also writes the 1 bit/px `normalized <= 0.9` image the expand launch reads."""
     src = 2 if fused_u16 else 4
     s = [n]
     for _ in range(levels):
         s.append((s[-1] + 1) // 2)
     p = [v * v for v in s]
     rest = range(1, levels)
+    rb_rest = [i for i in rest if fused_rb >= 2 and s[i] % 8 == 0 and s[i] >= 8]
+    mask = p[0] / 8.0 if le090 else 0.0
+    raw_in_expand = src if (fused_gradhist and not le090) else 0
     return {
         "minmax": 2 * p[0] * batch,
         "normalize": 6 * p[0] * batch,
-        "reduce_l0": ((src + 4) * p[0] + 4 * p[1]) * batch if fused_rb else (src * p[0] + 4 * p[1]) * batch,   # read S^2 once (u16 when fused), write (S/2)^2 f32 once
-                                                                         # (+ the band image when reduce and band are one launch)
-        "reduce_rest": sum(4 * p[i] + 4 * p[i + 1] for i in rest) * batch / max(1, len(rest)),
+        # read S^2 once (u16 when fused), write (S/2)^2 f32 once (+ the band image and the <= 0.9 bits when reduce and band are one launch)
+        "reduce_l0": ((src + 4) * p[0] + 4 * p[1] + mask) * batch if fused_rb else (src * p[0] + 4 * p[1]) * batch,
+        "reduce_rest": sum((8 if i in rb_rest else 4) * p[i] + 4 * p[i + 1] for i in rest) * batch / max(1, len(rest)),
         "band_l0": ((src + 4) * p[0] + 4 * p[1]) * batch,                # read fine + coarse, write band
-        "band_rest": sum(8 * p[i] + 4 * p[i + 1] for i in rest) * batch / max(1, len(rest)),
+        "band_rest": sum(8 * p[i] + 4 * p[i + 1] for i in rest if i not in rb_rest) * batch / max(1, len(rest) - len(rb_rest)),
         "sdev_hist": sum(8 * p[i] for i in range(4)) * batch / 4.0,      # read band, write sdev (hist in LDS)
-        "expand_l0": ((12 + (src if fused_gradhist else 0)) * p[0] + 4 * p[1]) * batch,   # read band + sdev + coarse (+ raw), write recon
+        "expand_l0": ((12 + raw_in_expand) * p[0] + 4 * p[1] + (mask if fused_gradhist else 0)) * batch,   # read band + sdev + coarse (+ raw or bits), write recon
         "expand_rest": (sum(12 * p[i] + 4 * p[i + 1] for i in range(1, 4)) +
                         sum(8 * p[i] + 4 * p[i + 1] for i in range(4, levels))) * batch / max(1, len(rest)),
-        "grad_hist": (4 + src) * p[0] * batch,                           # read recon + normalized (or raw)
+        "grad_hist": 0 if fused_gradhist else (4 + src) * p[0] * batch,  # read recon + normalized (or raw); fused: the launch only recounts images with exact zeros
         "grad_apply": 8 * p[0] * batch,                                  # read recon, write graded
         "curves": 4 * 2048 * 4 * batch,
         "cnr": 8 * p[3] * batch,
@@ -304,7 +310,9 @@ def main():
         mpix = world * batch * n * n * args.steps / 1e6
         ms_per_step = elapsed / args.steps * 1e3
         fused = (n % 8 == 0) and os.environ.get("MUSICA_U16", "1") != "0"
-        ab = algorithmic_bytes(n, levels, batch, fused, fused_gradhist=proc.fuses_gradhist(), fused_rb=proc.fuses_reduce_band())
+        rb_mode = int(os.environ.get("MUSICA_FUSE_RB", "2")) if proc.fuses_reduce_band() else 0
+        le090 = bool(proc.fuses_gradhist() and rb_mode >= 1 and os.environ.get("MUSICA_LE090", "1") != "0")
+        ab = algorithmic_bytes(n, levels, batch, fused, fused_gradhist=proc.fuses_gradhist(), fused_rb=rb_mode, le090=le090)
         kernels = {}
         total_kernel_us = 0.0
         for name, (us, cnt) in prof.items():

@@ -60,7 +60,7 @@ def main():
     # keys bench.py reads
     c4 = {}
     for k, v in kernels.items():
-        if k.startswith("musica::k_reduce_u16_pf"):
+        if k.startswith("musica::k_reduce_u16_pf") or "k_reduce_band<true>" in k:   # the level-0 launch of the metric kernel (alone, or fused with the band)
             c4["reduce_l0_hbm_bytes_per_launch"] = v["hbm_bytes_per_launch"]
         if "k_reduce_fast_pf<1, 2" in k:
             res["standalone_4096_warm_hbm_bytes_per_launch"] = v["hbm_bytes_per_launch"]
