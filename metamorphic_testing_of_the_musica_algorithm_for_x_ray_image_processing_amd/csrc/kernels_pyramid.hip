@@ -685,9 +685,11 @@ struct LutLds {
     float inv_w;
     uint32_t ok;
 };
-__device__ __noinline__ float curve_eval_slow(const CurveLds* t, float s) { return curve_eval(*t, s); }
-__device__ __forceinline__ float curve_eval_lut(const CurveLds& t, const LutLds& lut, bool lut_ok, float s) {
-    if (!lut_ok) return curve_eval_slow(&t, s);  // wave-uniform
+// LUTOK is wave-uniform and decided once per wavefront (k_expand_fast picks the instantiation of the whole march): a per-texel
+// `if (!ok) slow()` put a divergent branch and a call sequence around each of the 16 lookups of a trip.
+template <bool LUTOK>
+__device__ __forceinline__ float curve_eval_lut(const CurveLds& t, const LutLds& lut, float s) {
+    if (!LUTOK) return curve_eval(t, s);
     const float sf = fminf(s, 2.0f);
     const float kf = sf * lut.inv_w;
     const int fine = (int)kf;                                                    // only used when kf < 256 (kf >= 0 there)
@@ -708,27 +710,11 @@ __device__ __forceinline__ float curve_eval_lut(const CurveLds& t, const LutLds&
 // is 8 here, so a lane's 8 columns and both rows of a pair sit under one cnr texel), `normalized <= 0.9` on the raw pixel.
 // MASK: `normalized <= 0.9` comes as the bit image k_reduce_band<true> wrote (2 bytes per lane and row pair) instead of raw pixels
 // against thr090 (32 bytes).
-template <int GAIN, bool NR, int T, bool GH, int W = 1, bool MASK = false>
-__global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) {
-    __shared__ CurveLds tab;
-    __shared__ __attribute__((aligned(16))) LutLds lut;
-    // four bank-staggered copies of the histogram (lane l adds into copy l % 4, see sdev_parts.h: neighbouring texels share bins,
-    // and lanes of one ds_add that hit the same address are served one after the other); word 1024 of a copy takes what is out of range
+// CNR48: the cnr scale is 4 or 8 (levels 1 and 0 of every image side that is a multiple of 8): columns c..c+3 and c+4..c+7 of a
+// lane each sit under one cnr texel. Wave-uniform like LUTOK and chosen the same way (the other form divides per texel).
+template <int GAIN, bool NR, int T, bool GH, bool MASK, bool LUTOK, bool CNR48>
+__device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds& tab, const LutLds& lut, uint32_t* lh, int img) {
     constexpr int kGhCopies = 4, kGhStride = MUSICA_GRAD_BINS + 8;
-    __shared__ uint32_t lh[GH ? kGhCopies * kGhStride : 1];
-    const int img = blockIdx.z;
-    if (GH)
-        for (int i = threadIdx.x; i < kGhCopies * kGhStride; i += blockDim.x) lh[i] = 0u;
-    if (GAIN == GAIN_CURVE) {
-        const DevCurve* cv = a.curves + (size_t)img * a.curve_stride;
-        const DevCurveLut* lv = a.luts + (size_t)img * MUSICA_COARSER_LEVELS_START;
-        curve_to_lds(tab, cv);
-        for (int i = threadIdx.x; i < kLutBuckets + kLutCoarse; i += blockDim.x) lut.bucket[i] = lv->bucket[i];
-        for (int i = threadIdx.x; i <= kLutPoints; i += blockDim.x) lut.seg[i] = lv->seg[i];
-        if (threadIdx.x == 0) { lut.inv_w = lv->inv_w; lut.ok = lv->ok; }
-        __syncthreads();
-    }
-    const bool lut_ok = GAIN == GAIN_CURVE && lut.ok != 0;
     // slope of noise_reduction.comp:28, the same value for every texel
     const float nr_m = (a.highFactor - a.lowFactor) / (a.highCnr - a.lowCnr);
     const int lane = threadIdx.x & 63;
@@ -738,6 +724,7 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
     if (k0 < a.Sc) {   // wave-uniform
     const int k1 = min(k0 + a.rows_per_wave, a.Sc);
     const int S = a.S;
+    const int cnrScale = GH ? 8 : a.cnrScale;   // the launcher takes the GH variant only at scale 8
     const Buf bb = make_buf(a.band + (size_t)img * a.plane, a.plane * 4);
     const Buf sb = make_buf((GAIN != GAIN_CONST ? a.sdev : a.band) + (size_t)img * a.plane, a.plane * 4);
     const Buf ob = make_buf(a.recon + (size_t)img * a.plane, a.plane * 4);
@@ -749,7 +736,7 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
     const uint32_t moff = g.off == kOob ? kOob : (uint32_t)g.c >> 2, mrb = (uint32_t)S >> 2;
     const uint32_t urb = (uint32_t)S * 2u, uoff = g.off == kOob ? kOob : g.off >> 1;
     // noise reduction: the 8 columns of a lane share ceil(8 / scale) cnr texels per row
-    const int cxs[2] = {g.active ? g.c / a.cnrScale : 0, g.active ? (g.c + 4) / a.cnrScale : 0};
+    const int cxs[2] = {g.active ? g.c / cnrScale : 0, g.active ? (g.c + 4) / cnrScale : 0};
     // gradation histogram: img_relevant.comp:46-49 in uint arithmetic (wraps for N < 100 like the shader)
     const uint32_t border = 100u, lim = (uint32_t)S - border;
     uint32_t colin = 0u;
@@ -793,8 +780,8 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
                 float fe[8], fo[8];  // noise-reduction factors of the two rows
                 float cnr_pair = 0.0f;   // cnr * 256 of the texel above this lane's row pair (GH: scale 8)
                 if (NR) {
-                    const size_t re = (size_t)((2 * kk) / a.cnrScale) * a.cnrPitch, ro = (size_t)((2 * kk + 1) / a.cnrScale) * a.cnrPitch;
-                    if (a.cnrScale == 4 || a.cnrScale == 8) {  // columns c..c+3 and c+4..c+7 each sit inside one cnr texel (c % 8 == 0)
+                    const size_t re = (size_t)((2 * kk) / cnrScale) * a.cnrPitch, ro = (size_t)((2 * kk + 1) / cnrScale) * a.cnrPitch;
+                    if (CNR48) {  // columns c..c+3 and c+4..c+7 each sit inside one cnr texel (c % 8 == 0)
                         cnr_pair = cnr[re + cxs[0]] * kMaxCnrValue;
                         const float e0 = nr_factor_m(cnr_pair, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
                         const float e1 = nr_factor_m(cnr[re + cxs[1]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
@@ -805,7 +792,7 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
-                            const int cx = g.active ? (g.c + j) / a.cnrScale : 0;                 // noise_reduction.comp:39-45
+                            const int cx = g.active ? (g.c + j) / cnrScale : 0;                 // noise_reduction.comp:39-45
                             fe[j] = nr_factor_m(cnr[re + cx] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
                             fo[j] = nr_factor_m(cnr[ro + cx] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
                         }
@@ -823,7 +810,7 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
                         // contrast_curve_apply.comp:61
-                        float p = b[j] * (GAIN == GAIN_CURVE ? curve_eval_lut(tab, lut, lut_ok, sd[j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? sd[j] : 0.0f, a.high, tab));
+                        float p = b[j] * (GAIN == GAIN_CURVE ? curve_eval_lut<LUTOK>(tab, lut, sd[j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? sd[j] : 0.0f, a.high, tab));
                         if (NR) p = p * f[j];   // noise_reduction.comp:57
                         b[j] = low[j] + p;      // img_addition.comp:15
                     }
@@ -855,6 +842,37 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
         cw[0] = cw[T]; cw[1] = cw[T + 1];
     }
     }
+    return saw_zero;
+}
+
+template <int GAIN, bool NR, int T, bool GH, int W = 1, bool MASK = false>
+__global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) {
+    __shared__ CurveLds tab;
+    __shared__ __attribute__((aligned(16))) LutLds lut;
+    // four bank-staggered copies of the histogram (lane l adds into copy l % 4, see sdev_parts.h: neighbouring texels share bins,
+    // and lanes of one ds_add that hit the same address are served one after the other); word 1024 of a copy takes what is out of range
+    constexpr int kGhCopies = 4, kGhStride = MUSICA_GRAD_BINS + 8;
+    __shared__ uint32_t lh[GH ? kGhCopies * kGhStride : 1];
+    const int img = blockIdx.z;
+    if (GH)
+        for (int i = threadIdx.x; i < kGhCopies * kGhStride; i += blockDim.x) lh[i] = 0u;
+    if (GAIN == GAIN_CURVE) {
+        const DevCurve* cv = a.curves + (size_t)img * a.curve_stride;
+        const DevCurveLut* lv = a.luts + (size_t)img * MUSICA_COARSER_LEVELS_START;
+        curve_to_lds(tab, cv);
+        for (int i = threadIdx.x; i < kLutBuckets + kLutCoarse; i += blockDim.x) lut.bucket[i] = lv->bucket[i];
+        for (int i = threadIdx.x; i <= kLutPoints; i += blockDim.x) lut.seg[i] = lv->seg[i];
+        if (threadIdx.x == 0) { lut.inv_w = lv->inv_w; lut.ok = lv->ok; }
+        __syncthreads();
+    }
+    // wave-uniform (one LDS word): readfirstlane tells the compiler so, and the whole march is instantiated per case
+    const bool lut_ok = GAIN != GAIN_CURVE || __builtin_amdgcn_readfirstlane((int)lut.ok) != 0;
+    const bool cnr48 = !NR || GH || a.cnrScale == 4 || a.cnrScale == 8;   // kernel argument: uniform
+    bool saw_zero;
+    if (lut_ok && cnr48) saw_zero = expand_march<GAIN, NR, T, GH, MASK, true, true>(a, tab, lut, lh, img);
+    else if (lut_ok) saw_zero = expand_march<GAIN, NR, T, GH, MASK, true, NR && !GH ? false : true>(a, tab, lut, lh, img);
+    else if (cnr48) saw_zero = expand_march<GAIN, NR, T, GH, MASK, GAIN != GAIN_CURVE, true>(a, tab, lut, lh, img);
+    else saw_zero = expand_march<GAIN, NR, T, GH, MASK, GAIN != GAIN_CURVE, NR && !GH ? false : true>(a, tab, lut, lh, img);
     if (GH) {
         if (saw_zero) atomicOr(&a.gzero[img], 1u);
         __syncthreads();
@@ -1007,7 +1025,7 @@ static void launch_expand_t(hipStream_t st, const ExpandArgs& a, int batch, bool
             else hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 1>), grid, dim3(kBlockThreads), 0, st, a);
         }
         else if (rows_per_trip >= 2) hipLaunchKernelGGL((k_expand_fast<GAIN, NR, 2, false>), grid, dim3(kBlockThreads), 0, st, a);
-        else hipLaunchKernelGGL((k_expand_fast<GAIN, NR, 1, false>), grid, dim3(kBlockThreads), 0, st, a);
+        else hipLaunchKernelGGL((k_expand_fast<GAIN, NR, 1, false, NR ? 4 : 1>), grid, dim3(kBlockThreads), 0, st, a);   // NR: 129 registers wanted, capped at 128 (4 wavefronts per SIMD)
     } else {
         hipLaunchKernelGGL((k_expand_generic<GAIN, NR>), generic_grid(a.S, batch), kGenericBlock, 0, st, a);
     }
