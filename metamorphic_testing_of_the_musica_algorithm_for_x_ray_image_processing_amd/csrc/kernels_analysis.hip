@@ -370,7 +370,7 @@ __device__ __forceinline__ void noise_curves_block(int level, int img, const uin
             }
         }
         if (inb > 2) sok = 0;
-        lut->bucket[k] = make_float4((float)jlo, xa, xb, 0.0f);
+        lut->bucket[k] = make_float4(__int_as_float(jlo * 16), xa, xb, 0.0f);   // 16 * jlo: the byte offset of seg[jlo]
     }
     if ((int)threadIdx.x <= kLutPoints) {   // segment table: same slopes as DevCurve::m (linearFunction, contrast_curve_apply.comp:22-25)
         const int j = threadIdx.x;

@@ -647,10 +647,12 @@ __global__ void k_lowpass_generic(const float* __restrict__ coarse, float* __res
 // ======================================================================================
 
 // linearFunction() of noise_reduction.comp:24-31 with its slope m = (p2.y - p1.y) / (p2.x - p1.x) precomputed.
+// selects, not branches (a NaN c fails both tests and yields m * NaN + lowFactor = NaN, like the if / else chain)
 __device__ __forceinline__ float nr_factor_m(float c, float lowCnr, float lowFactor, float highCnr, float highFactor, float m) {
-    if (c < lowCnr) return lowFactor;
-    else if (c > highCnr) return highFactor;
-    return m * c + lowFactor;
+    float r = m * c + lowFactor;
+    r = c > highCnr ? highFactor : r;
+    r = c < lowCnr ? lowFactor : r;
+    return r;
 }
 // linearFunction() of noise_reduction.comp:24-31 — m * x, not m * (x - p1.x).
 __device__ __forceinline__ float nr_factor(float c, float lowCnr, float lowFactor, float highCnr, float highFactor) {
@@ -692,11 +694,16 @@ __device__ __forceinline__ float curve_eval_lut(const CurveLds& t, const LutLds&
     if (!LUTOK) return curve_eval(t, s);
     const float sf = fminf(s, 2.0f);
     const float kf = sf * lut.inv_w;
-    const int fine = (int)kf;                                                    // only used when kf < 256 (kf >= 0 there)
-    const int coarse = kLutBuckets + (int)fminf(sf * 256.0f, (float)(kLutCoarse - 1));
-    const float4 e = lut.bucket[kf < (float)kLutBuckets ? max(fine, 0) : max(coarse, kLutBuckets)];
-    const int j = (int)e.x + (e.y < sf ? 1 : 0) + (e.z < sf ? 1 : 0);
-    const float4 g = lut.seg[j];
+    // bucket index without a branch: the fine bucket int(kf) when kf < 256, else the coarse bucket 256 + int(min(sf * 256, 257)).
+    // The selection happens on the floats (both are <= 257, so one conversion serves either) and the +256 on the integers —
+    // the same values as converting each on its own. A negative kf (s < 0) clamps to bucket 0; its result is replaced below.
+    const bool in_fine = kf < (float)kLutBuckets;
+    const float tsel = in_fine ? kf : fminf(sf * 256.0f, (float)(kLutCoarse - 1));
+    const int idx = max((int)tsel + (in_fine ? 0 : kLutBuckets), 0);
+    const float4 e = lut.bucket[idx];
+    // e.x holds 16 * jlo as an integer (the byte offset of seg[jlo]); each abscissa of the bucket below sf moves one entry on
+    const int joff = __float_as_int(e.x) + (e.y < sf ? 16 : 0) + (e.z < sf ? 16 : 0);
+    const float4 g = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(lut.seg) + joff);
     const float r = g.z * (sf - g.x) + g.y;
     return sf < 0.0f ? 0.0f : r;
 }

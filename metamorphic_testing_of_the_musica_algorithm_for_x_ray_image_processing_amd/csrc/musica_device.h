@@ -69,7 +69,7 @@ struct DevCurveLut {
     float inv_w;
     uint32_t ok;
     uint32_t pad0, pad1;
-    float4 bucket[kLutBuckets + kLutCoarse];   // {jlo (as float), xa, xb, unused}
+    float4 bucket[kLutBuckets + kLutCoarse];   // {16 * jlo (integer bits: byte offset of seg[jlo]), xa, xb, unused}
     float4 seg[kLutPoints + 1];                 // seg[j] = {x[j-1], y[j-1], slope[j-1], 0}; seg[0] = {x[0], y[0], 0, 0}; seg[33] = 0
 };
 
