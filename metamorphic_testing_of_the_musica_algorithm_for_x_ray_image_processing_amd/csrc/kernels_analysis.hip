@@ -186,7 +186,7 @@ __global__ void k_sqrt(const uint16_t* __restrict__ px, float* __restrict__ out,
 // cov = (imageSize / 512) * 512: the part of the grid the reference's dispatch covers (src/vk_processing.cpp:2293-2295).
 // Software-pipelined form: one row per trip; the raw row of trip y+1 is requested before trip y is
 // computed and squared only when it enters the window (so the request never blocks the arithmetic).
-template <bool HIST>
+template <bool HIST, bool A8>
 __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
                                                                 size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov,
                                                                 int rows_per_wave) {
@@ -196,26 +196,31 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __r
     const int img = blockIdx.z;
     const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
     sdev += (size_t)img * plane;
+    const Buf db = make_buf(sdev, plane * 4);
     const int lane = threadIdx.x & 63;
-    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int seg = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
     const int y0 = seg * rows_per_wave;
     const SCfg g = make_scfg(blockIdx.x, lane, S);
     const uint32_t rb = (uint32_t)pitch * 4u;
     auto roff = [&](int row) -> uint32_t { return (row >= 0 && row < S) ? (uint32_t)row * rb : kOob; };
     if (y0 < S) {
         const int y1 = min(y0 + rows_per_wave, S);
+        // (Five window slots used round-robin in a trip unrolled five times — no `w0 = w1; ...` copies, 68 of the 284 vector
+        // instructions of a row — was measured and dropped: 116 registers instead of 96, 4 wavefronts per SIMD instead of 5,
+        // and the launch is 6 % slower.)
         SRow w0, w1, w2, w3, w4;
         SRaw raw;
-        load_srow(w0, bb, roff(y0 - 2), g, S);
-        load_srow(w1, bb, roff(y0 - 1), g, S);
-        load_srow(w2, bb, roff(y0), g, S);
-        load_srow(w3, bb, roff(y0 + 1), g, S);
+        load_srow<A8>(w0, bb, roff(y0 - 2), g, S);
+        load_srow<A8>(w1, bb, roff(y0 - 1), g, S);
+        load_srow<A8>(w2, bb, roff(y0), g, S);
+        load_srow<A8>(w3, bb, roff(y0 + 1), g, S);
         load_sraw(raw, bb, roff(y0 + 2), g);
-        bool alive[8] = {false, false, false, false, false, false, false, false};
+        unsigned long long alive[8], start[8];
+        sdev_start_masks(start, alive, g, cov);
         for (int y = y0; y < y1; y++) {
-            square_srow(w4, raw, g, S);
+            square_srow<A8>(w4, raw, g, S);
             load_sraw(raw, bb, roff(y + 3), g);  // rows past the image carry an out-of-range offset: no access
-            sdev_row<HIST>(w0, w1, w2, w3, w4, g, S, y, cov, sdev + (size_t)y * pitch, lh, alive);
+            sdev_row<HIST, A8>(w0, w1, w2, w3, w4, g, S, y, cov, sdev + (size_t)y * pitch, db, (uint32_t)y * rb, lh, alive, start);
             w0 = w1; w1 = w2; w2 = w3; w3 = w4;
         }
     }
@@ -533,7 +538,8 @@ void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const Leve
     const int strips = (l.S + kStripCols - 1) / kStripCols;
     const int segs = (l.S + rows_per_wave - 1) / rows_per_wave;
     const dim3 grid(strips, (segs + kWavesPerBlock - 1) / kWavesPerBlock, batch);
-    hipLaunchKernelGGL((k_sdev_hist_pf<true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
+    if ((l.S & 7) == 0) hipLaunchKernelGGL((k_sdev_hist_pf<true, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
+    else hipLaunchKernelGGL((k_sdev_hist_pf<true, false>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
 }
 
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch) {

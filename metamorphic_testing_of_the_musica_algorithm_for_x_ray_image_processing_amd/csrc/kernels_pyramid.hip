@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_fast_pf(const float* _
                                                                   int S, int pitch, size_t in_plane, int So, int opitch,
                                                                   size_t out_plane, int rows_per_wave) {
     const int lane = threadIdx.x & 63;
-    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int seg = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
     const int yo0 = seg * rows_per_wave;
     if (yo0 >= So) return;  // wave-uniform
     const int yo1 = min(yo0 + rows_per_wave, So);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_u16_pf(const uint16_t*
                                                                  int So, int opitch, size_t out_plane, int rows_per_wave,
                                                                  const uint32_t* __restrict__ minmax, int min_chain_exact) {
     const int lane = threadIdx.x & 63;
-    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int seg = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
     const int yo0 = seg * rows_per_wave;
     if (yo0 >= So) return;  // wave-uniform
     const int yo1 = min(yo0 + rows_per_wave, So);
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_band_fast(const float* __rest
                                                              int Sc, int cpitch, size_t cplane, int rows_per_wave,
                                                              const uint32_t* __restrict__ minmax, int min_chain_exact) {
     const int lane = threadIdx.x & 63;
-    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int seg = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
     const int k0 = seg * rows_per_wave;
     if (k0 >= Sc) return;
     const int k1 = min(k0 + rows_per_wave, Sc);
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __
                                                                int rows_per_wave, const uint32_t* __restrict__ minmax, int min_chain_exact,
                                                                uint16_t* __restrict__ le090) {
     const int lane = threadIdx.x & 63;
-    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int seg = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
     const int k0 = seg * rows_per_wave;
     if (k0 >= Sc) return;  // wave-uniform
     const int k1 = min(k0 + rows_per_wave, Sc);
@@ -725,7 +725,7 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
     // slope of noise_reduction.comp:28, the same value for every texel
     const float nr_m = (a.highFactor - a.lowFactor) / (a.highCnr - a.lowCnr);
     const int lane = threadIdx.x & 63;
-    const int seg = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int seg = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
     const int k0 = seg * a.rows_per_wave;
     bool saw_zero = false;
     if (k0 < a.Sc) {   // wave-uniform

@@ -78,22 +78,34 @@ __device__ __forceinline__ void load_sraw(SRaw& r, const Buf& b, uint32_t row_of
     r.l = bload2(b, (g.off_l + row_off) | ((g.off_l | row_off) & kOob));
     r.h = bload2(b, (g.off_r + row_off) | ((g.off_r | row_off) & kOob));
 }
+// A8: the side is a multiple of 8, so a lane's 8 columns are all inside the image or all outside (then every load of the lane is
+// out of range and reads 0) and the right-halo pair c+8, c+9 likewise: no per-column masks.
+template <bool A8>
 __device__ __forceinline__ void square_srow(SRow& r, const SRaw& w, const SCfg& g, int S) {
     const float v[8] = {w.a.x, w.a.y, w.a.z, w.a.w, w.d.x, w.d.y, w.d.z, w.d.w};
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const float t = j < g.valid ? v[j] : 0.0f;
+        const float t = (A8 || j < g.valid) ? v[j] : 0.0f;
         r.q[j] = t * t;
     }
     r.l0 = w.l.x * w.l.x; r.l1 = w.l.y * w.l.y;
     r.h0 = w.h.x * w.h.x;
-    const float h1 = (g.c + 9 < S) ? w.h.y : 0.0f;
+    const float h1 = (A8 || g.c + 9 < S) ? w.h.y : 0.0f;
     r.h1 = h1 * h1;
 }
+template <bool A8>
 __device__ __forceinline__ void load_srow(SRow& r, const Buf& b, uint32_t row_off, const SCfg& g, int S) {
     SRaw w;
     load_sraw(w, b, row_off, g);
-    square_srow(r, w, g, S);
+    square_srow<A8>(r, w, g, S);
+}
+
+// `mask` is a wave-uniform lane mask (an SGPR pair): lane l gets if_set when bit l is set. Written as the one instruction it
+// is — `(mask >> lane) & 1` costs a 64-bit shift, an AND and a compare per use.
+__device__ __forceinline__ uint32_t select_by_lane_mask(unsigned long long mask, uint32_t if_set, uint32_t if_clear) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
 }
 
 __device__ __forceinline__ float sum5(float a, float b, float c, float d, float e) {
@@ -105,10 +117,14 @@ __device__ __forceinline__ float sum5(float a, float b, float c, float d, float 
     return acc;
 }
 
-// One output row of sdev from its five rows of squares + the histogram scan of that row.
-template <bool HIST>
+// One output row of sdev from its five rows of squares + the histogram scan of that row. y is wave-uniform.
+// alive[j] / start[j]: lane masks (wave-uniform 64-bit values, i.e. scalar registers) — bit l = the run of column c + j of lane l
+// is still counting / starts alive. As per-lane bools the compiler packed them into bytes of two vector registers and spent
+// ~7 vector instructions per texel unpacking, re-arming and repacking them; as lane masks the bookkeeping is two scalar ANDs.
+template <bool HIST, bool A8>
 __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const SRow& r2, const SRow& r3, const SRow& r4, const SCfg& g, int S,
-                                         int y, int cov, float* __restrict__ drow, uint32_t* lh, bool (&alive)[8]) {
+                                         int y, int cov, float* __restrict__ drow, const Buf& db, uint32_t row_off, uint32_t* lh,
+                                         unsigned long long (&alive)[8], const unsigned long long (&start)[8]) {
     float q[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) q[j] = sum5(r0.q[j], r1.q[j], r2.q[j], r3.q[j], r4.q[j]);
@@ -131,7 +147,10 @@ __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const S
 #pragma unroll
     for (int j = 0; j < 8; j++) s[j] = musica_div25(s[j]);  // img_sdev.comp:30 (exact x / 25, exact_math.h)
     musica_sqrt8(s);                                         // img_sdev.comp:30 (exact sqrt, exact_math.h)
-    if (g.valid == 8) {
+    if (A8) {   // whole 16-byte groups, lanes outside the image carry out-of-range offsets: no branch
+        bstore4(db, (g.off0 + row_off) | (g.off0 & kOob), make_float4(s[0], s[1], s[2], s[3]));
+        bstore4(db, (g.off1 + row_off) | (g.off1 & kOob), make_float4(s[4], s[5], s[6], s[7]));
+    } else if (g.valid == 8) {
         *reinterpret_cast<float4*>(drow + g.c) = make_float4(s[0], s[1], s[2], s[3]);
         *reinterpret_cast<float4*>(drow + g.c + 4) = make_float4(s[4], s[5], s[6], s[7]);
     } else {
@@ -145,15 +164,24 @@ __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const S
     // outside the image / the dispatch coverage start every run dead (their texel would read 0 -> break).
     if (HIST && y < cov) {
         const int lane = threadIdx.x & 63;
-        const int copy = (lane % kHistCopies) * kHistCopyStride, scratch = kHistCopies * kHistCopyStride + lane;
+        const uint32_t copy_b = (uint32_t)((lane % kHistCopies) * kHistCopyStride) * 4u, scratch_b = (uint32_t)(kHistCopies * kHistCopyStride + lane) * 4u;
         const bool rearm = (y & (kHistArea - 1)) == 0;   // wave-uniform
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int bin = musica_noise_bin(s[j]);                           // 0 = break (:29, :33, :39); exact (exact_math.h)
-            const bool start = j < g.valid && g.c + j < cov;
-            alive[j] = (rearm ? start : alive[j]) && bin != 0;
-            atomicAdd(&lh[alive[j] ? copy + bin : scratch], 1u);              // :45
+            alive[j] = (rearm ? start[j] : alive[j]) & __ballot(bin != 0);
+            const uint32_t addr = select_by_lane_mask(alive[j], copy_b + (uint32_t)bin * 4u, scratch_b);
+            atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lh) + addr), 1u);   // :45
         }
+    }
+}
+
+// start[j] of sdev_row for this lane set: bit l = column c + j of lane l is inside the image and the dispatch coverage.
+__device__ __forceinline__ void sdev_start_masks(unsigned long long (&start)[8], unsigned long long (&alive)[8], const SCfg& g, int cov) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        start[j] = __ballot(j < g.valid && g.c + j < cov);
+        alive[j] = 0ull;
     }
 }
 
