@@ -41,7 +41,7 @@ def gather_rows(local_rows, world, dist=None, device=None):
     else:
         t = local_rows
     if world == 1 or dist is None:
-        return t.clone()
+        return t                 # one rank: the rows are the job's rows (no copy, no kernel)
     if t.is_cuda and dist.get_backend() == "gloo":
         # one-GPU rehearsal of the multi-rank flow (bench.py --backend gloo): the rows travel through host memory
         parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]

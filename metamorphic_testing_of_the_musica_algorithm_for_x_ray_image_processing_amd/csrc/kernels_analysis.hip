@@ -454,30 +454,30 @@ __global__ void k_cnr(const float* __restrict__ sdev, float* __restrict__ cnr, i
 // Per-image summary (musica_stats) written on the device so the batch driver can all-gather it with
 // RCCL without a host round trip. mean_cnr = mean(cnr image) * 256 — what test/mean_cnr/script.py:13-24
 // prints for a cnr.bmp dump — summed in double with a fixed partition and a fixed tree (deterministic).
-__global__ __launch_bounds__(256) void k_stats(const float* __restrict__ cnr, int S, int pitch, size_t plane,
-                                               const uint32_t* __restrict__ minmax, int min_chain_exact,
-                                               const musica_hist_max_point* __restrict__ noise_max, int levels,
-                                               const musica_hist_max_point* __restrict__ grad_max, const DevCurve* __restrict__ gcurve,
-                                               musica_stats* __restrict__ out, uint32_t image_id_base, uint32_t image_id_stride) {
-    __shared__ double part[256];
+__global__ __launch_bounds__(1024) void k_stats(const float* __restrict__ cnr, int S, int pitch, size_t plane,
+                                                const uint32_t* __restrict__ minmax, int min_chain_exact,
+                                                const musica_hist_max_point* __restrict__ noise_max, int levels,
+                                                const musica_hist_max_point* __restrict__ grad_max, const DevCurve* __restrict__ gcurve,
+                                                musica_stats* __restrict__ out, uint32_t image_id_base, uint32_t image_id_stride) {
+    __shared__ double part[1024];
     const int img = blockIdx.x;
     const float* p = cnr + (size_t)img * plane;
+    // 16 wavefronts, wavefront w sums rows w, w + 16, ... with its lanes across a row (coalesced), four rows in flight per trip;
+    // fixed partition + fixed tree = the same double sum on every run (one 256-thread block walking columns took 20 us)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     double acc = 0.0;
-    for (int x = threadIdx.x; x < S; x += blockDim.x) {
-        const float* col = p + x;
-        int y = 0;
-        for (; y + 8 <= S; y += 8) {   // eight independent loads in flight per thread (one per trip cost 115 us at S = 256)
-            float v[8];
+    for (int y = wv; y < S; y += 4 * nw) {
+        for (int x = lane; x < S; x += 64) {
+            float v[4];
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = col[(size_t)(y + k) * pitch];
+            for (int k = 0; k < 4; k++) v[k] = (y + k * nw < S) ? p[(size_t)(y + k * nw) * pitch + x] : 0.0f;
 #pragma unroll
-            for (int k = 0; k < 8; k++) acc += (double)v[k];
+            for (int k = 0; k < 4; k++) acc += (double)v[k];
         }
-        for (; y < S; y++) acc += (double)col[(size_t)y * pitch];
     }
     part[threadIdx.x] = acc;
     __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) {
+    for (int o = 512; o >= 1; o >>= 1) {
         if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
         __syncthreads();
     }
@@ -576,7 +576,7 @@ void launch_selftest_exact_math(hipStream_t st, unsigned long long* d_bad4) {
 void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact,
                   const musica_hist_max_point* noise_max, int levels, const musica_hist_max_point* grad_max, const DevCurve* gcurve,
                   musica_stats* out, uint32_t image_id_base, uint32_t image_id_stride, int batch) {
-    hipLaunchKernelGGL(k_stats, dim3(batch), dim3(256), 0, st, cnr, l3.S, l3.pitch, l3.plane, minmax, min_chain_exact, noise_max, levels,
+    hipLaunchKernelGGL(k_stats, dim3(batch), dim3(1024), 0, st, cnr, l3.S, l3.pitch, l3.plane, minmax, min_chain_exact, noise_max, levels,
                        grad_max, gcurve, out, image_id_base, image_id_stride);
 }
 
