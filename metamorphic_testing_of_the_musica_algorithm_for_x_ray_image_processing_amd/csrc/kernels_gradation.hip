@@ -332,46 +332,98 @@ __global__ __launch_bounds__(1024) void k_grad_curve(uint32_t* __restrict__ hist
 }
 
 // ---- K21 ------------------------------------------------------------------------------
+// getY() for a monotone polyline without a branch: j = #{x[i] < s} by a 6-step binary search over x[] padded with +inf (no
+// `probe <= count` test), one 16-byte read of seg[j] = {x[j-1], y[j-1], slope[j-1]} and curve_eval()'s arithmetic; j = 0 and
+// j >= count (and NaN, which counts 0) take curve_eval()'s `x[0] == s ? y[0] : 0`. Same values as curve_eval() for every s.
+struct GradLds {
+    float xs[kCurveCap];          // x[i], +inf at i >= count
+    float4 seg[kCurveCap + 1];    // seg[j] for 1 <= j < count; zeros elsewhere
+};
+__device__ __forceinline__ float grad_eval_mono(const GradLds& t, uint32_t last_b /* (count - 1) * 4 */, float x0, float y0, float s) {
+    uint32_t jb = 0u;   // 4 * j
+#pragma unroll
+    for (int step = kCurveCap / 2; step >= 1; step >>= 1) {
+        const float xv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(t.xs) + jb + (uint32_t)(step - 1) * 4u);
+        jb += xv < s ? (uint32_t)step * 4u : 0u;
+    }
+    const float4 g = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(t.seg) + jb * 4u);
+    const float r = g.z * (s - g.x) + g.y;
+    const float alt = s == x0 ? y0 : 0.0f;
+    return (jb - 4u) < last_b ? r : alt;   // 1 <= j <= count - 1
+}
+
+template <bool MONO>
+__device__ __forceinline__ float4 grad_eval4(const CurveLds& tab, const GradLds& gl, uint32_t last_b, float x0, float y0, float4 v) {
+    float4 o;
+    if (MONO) {
+        o.x = grad_eval_mono(gl, last_b, x0, y0, v.x);
+        o.y = grad_eval_mono(gl, last_b, x0, y0, v.y);
+        o.z = grad_eval_mono(gl, last_b, x0, y0, v.z);
+        o.w = grad_eval_mono(gl, last_b, x0, y0, v.w);
+    } else {
+        o.x = curve_eval(tab, v.x);                                      // img_apply_gradation_curve.comp:44
+        o.y = curve_eval(tab, v.y);
+        o.z = curve_eval(tab, v.z);
+        o.w = curve_eval(tab, v.w);
+    }
+    return o;
+}
+
+template <bool MONO, int U>
+__device__ __forceinline__ void grad_apply_loop(const CurveLds& tab, const GradLds& gl, const float4* __restrict__ src, float4* __restrict__ dst,
+                                                size_t i, size_t stride, size_t total, float4 (&v)[U]) {
+    const uint32_t last_b = tab.count ? (tab.count - 1u) * 4u : 0u;
+    const float x0 = tab.x[0], y0 = tab.y[0];
+    while (i < total) {
+        const size_t nxt = i + U * stride;
+        float4 w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (nxt + u * stride < total) w[u] = src[nxt + u * stride];   // the next trip's groups, in flight during the lookups
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (i + u * stride < total) dst[i + u * stride] = grad_eval4<MONO>(tab, gl, last_b, x0, y0, v[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = w[u];
+        i = nxt;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_grad_apply(const float* __restrict__ in, float* __restrict__ out, int N, int pitch, size_t plane,
                                                     const DevCurve* __restrict__ curves) {
     __shared__ CurveLds tab;
+    __shared__ __attribute__((aligned(16))) GradLds gl;
     const int img = blockIdx.z;
-    curve_to_lds(tab, curves + img);
-    __syncthreads();
     in += (size_t)img * plane;
     out += (size_t)img * plane;
     // rows are pitched to a multiple of 4 floats, so a plane is a dense run of 16-byte groups (pad columns are processed too:
-    // they hold zeros and nobody reads them). U groups per thread and trip, all loads issued before the first lookup: with one
-    // load in flight per lane the kernel is bound by latency, not bandwidth (4.7 TB/s; 8192 wavefronts x 1 KiB = 8 MB in flight).
-    constexpr int U = 4;
+    // they hold zeros and nobody reads them). U groups per thread and trip, all requested before the first lookup — and the
+    // first trip's before the curve is copied to LDS: a workgroup lives for one or two trips (the launcher sizes the grid so),
+    // and with the copy + barrier in front of the first load every workgroup started with ~1.5 us of nothing in flight
+    // (57.8 us per launch at C4 against 46 us for a plain 1:1 stream of the same bytes, devtools/stream11.hip).
+    constexpr int U = 2;
     const size_t total = (size_t)(pitch >> 2) * N;
     const float4* src = reinterpret_cast<const float4*>(in);
     float4* dst = reinterpret_cast<float4*>(out);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + (U - 1) * stride < total; i += U * stride) {
-        float4 v[U];
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) v[u] = src[i + u * stride];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            float4 o;
-            o.x = curve_eval(tab, v[u].x);                                      // img_apply_gradation_curve.comp:44
-            o.y = curve_eval(tab, v[u].y);
-            o.z = curve_eval(tab, v[u].z);
-            o.w = curve_eval(tab, v[u].w);
-            dst[i + u * stride] = o;
+    for (int u = 0; u < U; u++)
+        if (i + u * stride < total) v[u] = src[i + u * stride];
+    const DevCurve* cv = curves + img;
+    curve_to_lds(tab, cv);
+    {
+        const uint32_t count = cv->count;
+        for (int k = threadIdx.x; k <= kCurveCap; k += blockDim.x) {
+            if (k < kCurveCap) gl.xs[k] = (uint32_t)k < count ? cv->x[k] : __int_as_float(0x7F800000);
+            gl.seg[k] = (k >= 1 && (uint32_t)k < count) ? make_float4(cv->x[k - 1], cv->y[k - 1], cv->m[k - 1], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
-    for (; i < total; i += stride) {
-        const float4 v = src[i];
-        float4 o;
-        o.x = curve_eval(tab, v.x);
-        o.y = curve_eval(tab, v.y);
-        o.z = curve_eval(tab, v.z);
-        o.w = curve_eval(tab, v.w);
-        dst[i] = o;
-    }
+    __syncthreads();
+    // the tone curve is monotone unless t1 < ts ("Exactness notes"); one LDS word, the same for the whole workgroup
+    if (__builtin_amdgcn_readfirstlane((int)tab.monotone) != 0) grad_apply_loop<true, U>(tab, gl, src, dst, i, stride, total, v);
+    else grad_apply_loop<false, U>(tab, gl, src, dst, i, stride, total, v);
 }
 
 // ======================================================================================
@@ -410,8 +462,12 @@ void launch_grad_curve(hipStream_t st, uint32_t* hist, musica_hist_max_point* gm
 }
 
 void launch_grad_apply(hipStream_t st, const float* in, float* out, const LevelDesc& l0, const DevCurve* curves, int batch) {
+    // two 16-byte groups per thread and trip; ~16384 workgroups per launch is where a plain 1:1 stream peaks on this part
+    // (devtools/stream11.hip: 46 us for 2 x 134 MB; 2048 workgroups 52 us, 65536 51 us)
     const size_t total = (size_t)(l0.pitch >> 2) * l0.S;
-    int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)2048);
+    const size_t want = (total + 511) / 512;
+    const size_t cap = std::max<size_t>(16384 / (size_t)std::max(batch, 1), 256);
+    const int blocks = (int)std::max<size_t>(std::min(want, cap), 1);
     hipLaunchKernelGGL(k_grad_apply, dim3(blocks, 1, batch), dim3(256), 0, st, in, out, l0.S, l0.pitch, l0.plane, curves);
 }
 
