@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_minmax_u16(const uint16_t* __restrict__
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     us2 mn2 = {0xFFFFu, 0xFFFFu}, mx2 = {0u, 0u};
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < nvec; i += 4 * stride) {   // four independent 16-byte loads in flight per lane
+    for (; i + 3 * stride < nvec; i += 4 * stride) {   // four independent 16-byte loads in flight per lane (eight: no change, 22 us)
         const uint4 q0 = pv[i], q1 = pv[i + stride], q2 = pv[i + 2 * stride], q3 = pv[i + 3 * stride];
         minmax_acc(mn2, mx2, q0);
         minmax_acc(mn2, mx2, q1);

@@ -339,10 +339,12 @@ struct GradLds {
     float xs[kCurveCap];          // x[i], +inf at i >= count
     float4 seg[kCurveCap + 1];    // seg[j] for 1 <= j < count; zeros elsewhere
 };
+// STEP0: the first probe distance — 16 for curves of fewer than 32 points (the 22-point tone curve), 32 otherwise.
+template <int STEP0>
 __device__ __forceinline__ float grad_eval_mono(const GradLds& t, uint32_t last_b /* (count - 1) * 4 */, float x0, float y0, float s) {
     uint32_t jb = 0u;   // 4 * j
 #pragma unroll
-    for (int step = kCurveCap / 2; step >= 1; step >>= 1) {
+    for (int step = STEP0; step >= 1; step >>= 1) {
         const float xv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(t.xs) + jb + (uint32_t)(step - 1) * 4u);
         jb += xv < s ? (uint32_t)step * 4u : 0u;
     }
@@ -352,14 +354,14 @@ __device__ __forceinline__ float grad_eval_mono(const GradLds& t, uint32_t last_
     return (jb - 4u) < last_b ? r : alt;   // 1 <= j <= count - 1
 }
 
-template <bool MONO>
+template <int MONO>   // 0: literal scan, 16 / 32: branch-free search with that first probe distance
 __device__ __forceinline__ float4 grad_eval4(const CurveLds& tab, const GradLds& gl, uint32_t last_b, float x0, float y0, float4 v) {
     float4 o;
     if (MONO) {
-        o.x = grad_eval_mono(gl, last_b, x0, y0, v.x);
-        o.y = grad_eval_mono(gl, last_b, x0, y0, v.y);
-        o.z = grad_eval_mono(gl, last_b, x0, y0, v.z);
-        o.w = grad_eval_mono(gl, last_b, x0, y0, v.w);
+        o.x = grad_eval_mono<MONO ? MONO : 32>(gl, last_b, x0, y0, v.x);
+        o.y = grad_eval_mono<MONO ? MONO : 32>(gl, last_b, x0, y0, v.y);
+        o.z = grad_eval_mono<MONO ? MONO : 32>(gl, last_b, x0, y0, v.z);
+        o.w = grad_eval_mono<MONO ? MONO : 32>(gl, last_b, x0, y0, v.w);
     } else {
         o.x = curve_eval(tab, v.x);                                      // img_apply_gradation_curve.comp:44
         o.y = curve_eval(tab, v.y);
@@ -369,7 +371,7 @@ __device__ __forceinline__ float4 grad_eval4(const CurveLds& tab, const GradLds&
     return o;
 }
 
-template <bool MONO, int U>
+template <int MONO, int U>
 __device__ __forceinline__ void grad_apply_loop(const CurveLds& tab, const GradLds& gl, const float4* __restrict__ src, float4* __restrict__ dst,
                                                 size_t i, size_t stride, size_t total, float4 (&v)[U]) {
     const uint32_t last_b = tab.count ? (tab.count - 1u) * 4u : 0u;
@@ -422,8 +424,10 @@ __global__ __launch_bounds__(256) void k_grad_apply(const float* __restrict__ in
     }
     __syncthreads();
     // the tone curve is monotone unless t1 < ts ("Exactness notes"); one LDS word, the same for the whole workgroup
-    if (__builtin_amdgcn_readfirstlane((int)tab.monotone) != 0) grad_apply_loop<true, U>(tab, gl, src, dst, i, stride, total, v);
-    else grad_apply_loop<false, U>(tab, gl, src, dst, i, stride, total, v);
+    const int mono = __builtin_amdgcn_readfirstlane((int)tab.monotone), cnt = __builtin_amdgcn_readfirstlane((int)tab.count);
+    if (mono != 0 && cnt < 32) grad_apply_loop<16, U>(tab, gl, src, dst, i, stride, total, v);
+    else if (mono != 0) grad_apply_loop<32, U>(tab, gl, src, dst, i, stride, total, v);
+    else grad_apply_loop<0, U>(tab, gl, src, dst, i, stride, total, v);
 }
 
 // ======================================================================================
