@@ -462,17 +462,25 @@ __global__ __launch_bounds__(1024) void k_stats(const float* __restrict__ cnr, i
     __shared__ double part[1024];
     const int img = blockIdx.x;
     const float* p = cnr + (size_t)img * plane;
-    // 16 wavefronts, wavefront w sums rows w, w + 16, ... with its lanes across a row (coalesced), four rows in flight per trip;
-    // fixed partition + fixed tree = the same double sum on every run (one 256-thread block walking columns took 20 us)
+    // 16 wavefronts, wavefront w sums rows w, w + 16, ... with its lanes across a row (coalesced); 4 rows x 4 column chunks =
+    // 16 independent loads per trip (the cnr image of a 2048^2 input is 256^2: four trips per wavefront). Fixed partition + fixed
+    // tree = the same double sum on every run.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     double acc = 0.0;
     for (int y = wv; y < S; y += 4 * nw) {
-        for (int x = lane; x < S; x += 64) {
-            float v[4];
+        for (int xb = 0; xb < S; xb += 256) {
+            float v[4][4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = (y + k * nw < S) ? p[(size_t)(y + k * nw) * pitch + x] : 0.0f;
+            for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) acc += (double)v[k];
+                for (int c = 0; c < 4; c++) {
+                    const int yy = y + k * nw, xx = xb + c * 64 + lane;
+                    v[k][c] = (yy < S && xx < S) ? p[(size_t)yy * pitch + xx] : 0.0f;
+                }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc += (double)v[k][c];
         }
     }
     part[threadIdx.x] = acc;
