@@ -196,7 +196,8 @@ def main():
     except RuntimeError as e:
         raise SystemExit(str(e))
     pipe.upload(px)                                                # inputs resident in HBM (one copy per context) before the timed region
-    pipe.prime()                                                   # every context has captured its graph
+    pipe.prime()                                                   # every context has captured its graph; the best set of hardware queues is kept
+    queue_calibration = pipe.calibration
     if depth == 1:
         proc = pipe.contexts[0]
     else:                                                          # the per-kernel passes and the other measurements: one default (three-stream) context
@@ -444,6 +445,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "image_size": n, "levels": levels, "images_per_gpu_per_step": batch, "contexts_in_flight": depth,
+                       "queue_calibration_ms": queue_calibration,
                        "input": "seeded phantoms, %d-bit" % bits, "dispatch": "eager launches" if (kernel_events or os.environ.get("MUSICA_GRAPH", "1") == "0") else "hipGraph replay",
                        "kernel_events_in_timed_region": kernel_events, "sharding": "image k -> rank k mod N, no data-path collective",
                        "stats_gathered": int(st.shape[0]), "ranks_joined": world},

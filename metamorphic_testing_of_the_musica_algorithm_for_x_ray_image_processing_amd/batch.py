@@ -96,13 +96,21 @@ class ShardPipeline:
     (src/vk_processing.cpp:2104-2601); this is the batch driver's throughput form of it.
     """
 
-    def __init__(self, image_size, levels=0, batch=1, depth=3, flags=0, device=0):
+    HW_QUEUES = 4   # the HIP runtime's default number of hardware queues per process (GPU_MAX_HW_QUEUES)
+
+    def __init__(self, image_size, levels=0, batch=1, depth=3, flags=0, device=0, calibrate=True):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.contexts = []
         if depth > 1:
             flags |= FLAG_LINEAR
-        for _ in range(depth):
+        # Which hardware queue a stream lands on is the runtime's round-robin over every stream the process has created so far
+        # (torch, RCCL, ...), and the queues are not equal: on MI355X two of the four share a pipe and do not run side by side
+        # (three contexts on queues {0,1,2}: 0.364 ms per C4 step, on {1,2,3} or {2,3,0}: 0.407; two contexts on {2,3}: 0.455 — as
+        # slow as one). So one context per queue is created, prime() times every cyclic window of `depth` of them for a few
+        # steps and keeps the fastest; the others are destroyed.
+        n = self.HW_QUEUES if (calibrate and 1 < depth < self.HW_QUEUES) else depth
+        for _ in range(n):
             p = MusicaProcessing(device=device)
             if not p.init(image_size, levels=levels, batch=batch, flags=flags):
                 self.cleanup()
@@ -111,22 +119,55 @@ class ShardPipeline:
         self.depth = depth
         self.batch = batch
         self.steps = 0
+        self.calibration = None   # {first context of the window: ms per step} once prime() has chosen
 
     def upload(self, images):
-        """The shard resident in every context's input buffer (one array for all, or one per context)."""
+        """The shard resident in every context's input buffer (one array for all, or one per context in flight)."""
         per_ctx = isinstance(images, (list, tuple))
         if per_ctx and len(images) != self.depth:
-            raise ValueError("need one image batch per context")
+            raise ValueError("need one image batch per context in flight")
+        self._images = images
         for k, p in enumerate(self.contexts):
-            p.upload(images[k] if per_ctx else images)
+            p.upload(images[k % self.depth] if per_ctx else images)
 
-    def prime(self):
-        """Two untimed steps per context (the first captures its graph, the second replays it), then drain."""
+    def _run(self, use, steps):
+        for s in range(steps):
+            if not use[s % len(use)].execute_device():
+                raise RuntimeError("musica_execute_device failed: " + last_error())
+        for p in use:
+            p.sync()
+
+    def prime(self, calibration_steps=9):
+        """Two untimed steps per context (the first captures its graph, the second replays it), the choice of the contexts
+        that stay (see __init__), then drain."""
+        import time
         for _ in range(2):
+            self._run(self.contexts, len(self.contexts))
+        n = len(self.contexts)
+        if n > self.depth:
+            timing = {}
+            for first in range(n):
+                use = [self.contexts[(first + k) % n] for k in range(self.depth)]
+                self._run(use, self.depth)                       # warm this combination
+                best = None
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    self._run(use, calibration_steps)
+                    dt = (time.perf_counter() - t0) / calibration_steps * 1e3
+                    best = dt if best is None else min(best, dt)
+                timing[first] = round(best, 4)
+            first = min(timing, key=timing.get)
+            keep = [self.contexts[(first + k) % n] for k in range(self.depth)]
             for p in self.contexts:
-                if not p.execute_device():
-                    raise RuntimeError("musica_execute_device failed: " + last_error())
-        self.sync()
+                if not any(p is q for q in keep):
+                    p.cleanup()
+            self.contexts = keep
+            self.calibration = timing
+            if isinstance(self._images, (list, tuple)):          # one batch per context in flight: context k holds images[k]
+                for k, p in enumerate(self.contexts):
+                    p.upload(self._images[k])
+                self._run(self.contexts, self.depth)
+        self.steps = 0
 
     def step(self, d_pixels=None):
         """Enqueue one step (asynchronous) on the next context; returns that context."""
