@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __r
         const int y1 = min(y0 + rows_per_wave, S);
         // (Five window slots used round-robin in a trip unrolled five times — no `w0 = w1; ...` copies, 68 of the 284 vector
         // instructions of a row — was measured and dropped: 116 registers instead of 96, 4 wavefronts per SIMD instead of 5,
-        // and the launch is 6 % slower.)
+        // and the launch is 6 % slower. Two or four raw rows in flight per wavefront instead of one: no change either.)
         SRow w0, w1, w2, w3, w4;
         SRaw raw;
         load_srow<A8>(w0, bb, roff(y0 - 2), g, S);
