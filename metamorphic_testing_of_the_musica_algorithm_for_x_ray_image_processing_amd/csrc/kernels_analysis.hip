@@ -453,21 +453,18 @@ __global__ void k_cnr(const float* __restrict__ sdev, float* __restrict__ cnr, i
 
 // Per-image summary (musica_stats) written on the device so the batch driver can all-gather it with
 // RCCL without a host round trip. mean_cnr = mean(cnr image) * 256 — what test/mean_cnr/script.py:13-24
-// prints for a cnr.bmp dump — summed in double with a fixed partition and a fixed tree (deterministic).
-__global__ __launch_bounds__(1024) void k_stats(const float* __restrict__ cnr, int S, int pitch, size_t plane,
-                                                const uint32_t* __restrict__ minmax, int min_chain_exact,
-                                                const musica_hist_max_point* __restrict__ noise_max, int levels,
-                                                const musica_hist_max_point* __restrict__ grad_max, const DevCurve* __restrict__ gcurve,
-                                                musica_stats* __restrict__ out, uint32_t image_id_base, uint32_t image_id_stride) {
+// prints for a cnr.bmp dump — summed in double with a fixed partition and a fixed tree (deterministic):
+// k_stats_partial: nb workgroups per image, workgroup b sums the rows of its 16 wavefronts (wavefront b * 16 + w takes rows
+// b * 16 + w, + 16 nb, ...; lanes across a row, 4 rows x 4 column chunks = 16 independent loads per trip) into partial[img][b];
+// k_stats: one workgroup per image adds the nb partial sums in index order and fills the row. (One workgroup per image for
+// everything took 20 us for the 256^2 cnr image of a 2048^2 input and 440 us for the 1024^2 one of an 8192^2 input.)
+__global__ __launch_bounds__(1024) void k_stats_partial(const float* __restrict__ cnr, int S, int pitch, size_t plane, double* __restrict__ partial) {
     __shared__ double part[1024];
-    const int img = blockIdx.x;
+    const int img = blockIdx.y, nb = gridDim.x;
     const float* p = cnr + (size_t)img * plane;
-    // 16 wavefronts, wavefront w sums rows w, w + 16, ... with its lanes across a row (coalesced); 4 rows x 4 column chunks =
-    // 16 independent loads per trip (the cnr image of a 2048^2 input is 256^2: four trips per wavefront). Fixed partition + fixed
-    // tree = the same double sum on every run.
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x >> 6) * nb;
     double acc = 0.0;
-    for (int y = wv; y < S; y += 4 * nw) {
+    for (int y = blockIdx.x * (blockDim.x >> 6) + wv; y < S; y += 4 * nw) {
         for (int xb = 0; xb < S; xb += 256) {
             float v[4][4];
 #pragma unroll
@@ -489,6 +486,19 @@ __global__ __launch_bounds__(1024) void k_stats(const float* __restrict__ cnr, i
         if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
         __syncthreads();
     }
+    if (threadIdx.x == 0) partial[(size_t)img * nb + blockIdx.x] = part[0];
+}
+
+__global__ __launch_bounds__(64) void k_stats(const double* __restrict__ partial, int nb, int S,
+                                              const uint32_t* __restrict__ minmax, int min_chain_exact,
+                                              const musica_hist_max_point* __restrict__ noise_max, int levels,
+                                              const musica_hist_max_point* __restrict__ grad_max, const DevCurve* __restrict__ gcurve,
+                                              musica_stats* __restrict__ out, uint32_t image_id_base, uint32_t image_id_stride) {
+    const int img = blockIdx.x;
+    double part[1];
+    part[0] = 0.0;
+    if (threadIdx.x == 0)
+        for (int b = 0; b < nb; b++) part[0] += partial[(size_t)img * nb + b];
     if (threadIdx.x != 0) return;
     musica_stats st;
     st.image_id = image_id_base + (uint32_t)img * image_id_stride;
@@ -583,8 +593,11 @@ void launch_selftest_exact_math(hipStream_t st, unsigned long long* d_bad4) {
 
 void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact,
                   const musica_hist_max_point* noise_max, int levels, const musica_hist_max_point* grad_max, const DevCurve* gcurve,
-                  musica_stats* out, uint32_t image_id_base, uint32_t image_id_stride, int batch) {
-    hipLaunchKernelGGL(k_stats, dim3(batch), dim3(1024), 0, st, cnr, l3.S, l3.pitch, l3.plane, minmax, min_chain_exact, noise_max, levels,
+                  musica_stats* out, uint32_t image_id_base, uint32_t image_id_stride, int batch, double* partial /* [batch][kStatsMaxBlocks] */) {
+    const size_t px = (size_t)l3.S * l3.S;
+    const int nb = (int)std::min<size_t>(std::max<size_t>(px / 16384, 1), (size_t)kStatsMaxBlocks);
+    hipLaunchKernelGGL(k_stats_partial, dim3(nb, batch), dim3(1024), 0, st, cnr, l3.S, l3.pitch, l3.plane, partial);
+    hipLaunchKernelGGL(k_stats, dim3(batch), dim3(64), 0, st, (const double*)partial, nb, l3.S, minmax, min_chain_exact, noise_max, levels,
                        grad_max, gcurve, out, image_id_base, image_id_stride);
 }
 

@@ -83,9 +83,10 @@ void launch_curves_cnr(hipStream_t st, const uint32_t* hist, size_t hist_stride,
                        const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact, int* thr090, int lev0 = 0);
 void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& l3, const musica_hist_max_point* maxpts, int levels, int batch);
 void launch_selftest_exact_math(hipStream_t st, unsigned long long* d_bad4);
+constexpr int kStatsMaxBlocks = 64;
 void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact,
                   const musica_hist_max_point* noise_max, int levels, const musica_hist_max_point* grad_max, const DevCurve* gcurve,
-                  musica_stats* out, uint32_t image_id_base, uint32_t image_id_stride, int batch);
+                  musica_stats* out, uint32_t image_id_base, uint32_t image_id_stride, int batch, double* partial);
 // kernels_gradation.hip
 void launch_grad_hist(hipStream_t st, const GradArgs& a, int batch);
 void launch_grad_hist_ref(hipStream_t st, const float* img, const float* relevant, const LevelDesc& l0, uint32_t* hist, int batch);

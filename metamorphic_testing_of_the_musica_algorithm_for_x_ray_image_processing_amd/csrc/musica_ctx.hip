@@ -98,6 +98,7 @@ struct musica_ctx {
     uint32_t* d_grad_hist_b;   // the literal recount of images whose reconstruction holds an exact zero (fused gradation histogram)
     uint32_t* d_gzero;         // [B]: that condition
     int* d_thr090;             // [B]: raw-pixel form of `normalized <= 0.9`
+    double* d_stats_partial;   // [B][kStatsMaxBlocks]: partial sums of the cnr image (k_stats_partial -> k_stats)
     uint16_t* d_le090;         // [B][S1][S0 / 8] or null: its bit image, written by the level-0 reduce + band launch for the level-0 expand launch
     bool fuse_gh;              // the level-0 expand launch accumulates the gradation histogram
     int fuse_rb;               // smooth + downsample and the band-pass image of a level in one launch (k_reduce_band): 0 off, 1 level 0 only,
@@ -251,6 +252,7 @@ static musica_ctx* make_view(const musica_ctx* c, int i0, int nb) {
     v->d_grad_hist_b += o * MUSICA_GRAD_BINS;
     v->d_gzero += o;
     v->d_thr090 += o;
+    v->d_stats_partial += o * kStatsMaxBlocks;
     if (v->d_le090) v->d_le090 += o * (size_t)c->lv[1].S * (c->lv[0].S / 8);
     v->d_grad_max += o;
     v->d_gcurve += o;
@@ -454,6 +456,7 @@ static musica_ctx* create_impl(const musica_params* params) {
     ok = ok && dalloc(c, &c->d_grad_hist_b, B * MUSICA_GRAD_BINS);
     ok = ok && dalloc(c, &c->d_gzero, B);
     ok = ok && dalloc(c, &c->d_thr090, B);
+    ok = ok && dalloc(c, &c->d_stats_partial, B * kStatsMaxBlocks);
     c->d_le090 = nullptr;
     if (c->fuse_gh && c->fuse_rb >= 1 && env_int("MUSICA_LE090", 1) != 0) ok = ok && dalloc(c, &c->d_le090, B * (size_t)c->lv[1].S * (c->lv[0].S / 8));
     ok = ok && dalloc(c, &c->d_grad_max, B);
@@ -1032,7 +1035,7 @@ int musica_execute_stream(musica_ctx* c, const uint16_t* const* pixels, uint32_t
         ok = enqueue_all(c);
         if (ok && stats) {
             launch_stats(c->stream, c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_noise_max, c->L, c->d_grad_max, c->d_gcurve,
-                         d_rows + (size_t)j * c->B, j * (uint32_t)c->B, 1u, c->B);
+                         d_rows + (size_t)j * c->B, j * (uint32_t)c->B, 1u, c->B, c->d_stats_partial);
         }
         hipEventRecord(c->ev_consumed[k], c->stream);
     }
@@ -1273,7 +1276,7 @@ int musica_stats_device_strided(musica_ctx* c, void* d_dst, uint32_t image_id_ba
     CHECK_CTX(c);
     if (!d_dst) return fail("musica_stats_device: d_dst is NULL");
     launch_stats(c->stream, c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_noise_max, c->L, c->d_grad_max,
-                 c->d_gcurve, (musica_stats*)d_dst, image_id_base, image_id_stride, c->B);
+                 c->d_gcurve, (musica_stats*)d_dst, image_id_base, image_id_stride, c->B, c->d_stats_partial);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e));
     return 1;
