@@ -160,11 +160,111 @@ __global__ void k_clahe_apply(const float* __restrict__ in, float* __restrict__ 
     out[o] = combined;
 }
 
+// K24 again, for sides that are a multiple of 4: the same per-texel arithmetic, organised so that nothing is computed twice.
+//  * the 16 tiles' curve ordinates are staged in LDS (16 KB): getY() reads two of them per tile and a texel blends up to four
+//    tiles — 8 scattered global reads per texel in k_clahe_apply;
+//  * everything that depends on the column only (px = x / G with its float division, the base tile, the neighbour tile, the two
+//    horizontal weights 1 - |cx - px|) is computed once per thread — a thread owns 4 columns and walks kApplyRows rows — and
+//    everything that depends on the row only (py, by, the vertical neighbour and weights) once per row, where it is wave-uniform;
+//  * per texel remain the four getY() lookups and the blend, in the shader's order: (bx,by), (bx+sx,by), (bx,by+sy), (bx+sx,by+sy).
+constexpr int kApplyRows = 8;
+__device__ __forceinline__ float clahe_get_y_lds(const float* __restrict__ ys /* [kB] ordinates of one tile */, float s) {
+    int j = 0;
+    if (s > 0.0f) j = (int)fminf(ceilf(s * (float)kB), (float)(kB - 1));
+    if (s > 1.0f) j += 1;
+    if (j == 0) return (s == 0.0f) ? ys[0] : 0.0f;
+    if (j >= kB) return 0.0f;
+    const float y0 = ys[j - 1], y1 = ys[j], x0 = clahe_x(j - 1);
+    const float m = (y1 - y0) * (j == kB - 1 ? (float)(kB / 2) : (float)kB);
+    return m * (s - x0) + y0;
+}
+// one axis of clahe_grad_curve_apply.comp:45-79 for texel coordinate v: p = v / G, base b = uint(p) + 0.5, d = p - b, the
+// neighbour b + sign(d); tile indices (the base one unclamped for the d == 0 case, both clamped for the blend) and the
+// weights 1 - |c - p| of the two candidates.
+struct ClaheAxis {
+    float w0, w1;          // 1 - |b - p|, 1 - |(b + sign d) - p|
+    uint32_t t0, t1;       // clamped tile index of b and of b + sign d
+    uint32_t t0_raw;       // uint(floor(b)), unclamped (:63)
+    bool use;              // d != 0
+};
+__device__ __forceinline__ ClaheAxis clahe_axis(int v, uint32_t G) {
+    ClaheAxis a;
+    const float p = (float)v / (float)G;                                         // :45-48
+    const float b = (float)f2u(p) + 0.5f;                                        // :50-53
+    const float d = p - b;                                                       // :55-58
+    const float n = b + signf_(d);
+    a.use = d != 0.0f;
+    a.w0 = 1.0f - fabsf(b - p);
+    a.w1 = 1.0f - fabsf(n - p);
+    a.t0_raw = f2u(floorf(b));
+    a.t0 = min(a.t0_raw, (uint32_t)kT - 1u);                                     // :78-79
+    a.t1 = min(f2u(floorf(n)), (uint32_t)kT - 1u);
+    return a;
+}
+__device__ __forceinline__ float clahe_blend(const float* __restrict__ ys, float pixel, const ClaheAxis& ax, const ClaheAxis& ay) {
+    if (!ax.use && !ay.use) {                                                    // :61-66
+        if (ax.t0_raw < (uint32_t)kT && ay.t0_raw < (uint32_t)kT) return clahe_get_y_lds(ys + ((size_t)ax.t0_raw * kT + ay.t0_raw) * kB, pixel);
+        return 0.0f;
+    }
+    float combined = 0.0f;
+    if (ax.use && ay.use) {                                                      // :116-146: (bx,by) (bx+sx,by) (bx,by+sy) (bx+sx,by+sy)
+        combined += ax.w0 * ay.w0 * clahe_get_y_lds(ys + ((size_t)ax.t0 * kT + ay.t0) * kB, pixel);
+        combined += ax.w1 * ay.w0 * clahe_get_y_lds(ys + ((size_t)ax.t1 * kT + ay.t0) * kB, pixel);
+        combined += ax.w0 * ay.w1 * clahe_get_y_lds(ys + ((size_t)ax.t0 * kT + ay.t1) * kB, pixel);
+        combined += ax.w1 * ay.w1 * clahe_get_y_lds(ys + ((size_t)ax.t1 * kT + ay.t1) * kB, pixel);
+    } else if (ay.use) {                                                         // :68-88
+        combined += ay.w0 * clahe_get_y_lds(ys + ((size_t)ax.t0 * kT + ay.t0) * kB, pixel);
+        combined += ay.w1 * clahe_get_y_lds(ys + ((size_t)ax.t0 * kT + ay.t1) * kB, pixel);
+    } else {                                                                     // :94-114
+        combined += ax.w0 * clahe_get_y_lds(ys + ((size_t)ax.t0 * kT + ay.t0) * kB, pixel);
+        combined += ax.w1 * clahe_get_y_lds(ys + ((size_t)ax.t1 * kT + ay.t0) * kB, pixel);
+    }
+    return combined;
+}
+// grid: x = 1024-column chunks, y = bands of kApplyRows rows, z = batch
+__global__ __launch_bounds__(256) void k_clahe_apply4(const float* __restrict__ in, float* __restrict__ out, int N, int pitch, size_t plane,
+                                                      const musica_point* __restrict__ points) {
+    __shared__ float ys[kT * kT * kB];
+    const musica_point* P = points + (size_t)blockIdx.z * kT * kT * kB;
+    const int y0 = blockIdx.y * kApplyRows;
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const uint32_t G = (uint32_t)N / (uint32_t)kT;                               // :43
+    in += (size_t)blockIdx.z * plane;
+    out += (size_t)blockIdx.z * plane;
+    const bool active = x < N;
+    // the first row's group is requested before the ordinates are staged
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (active) v = *reinterpret_cast<const float4*>(in + (size_t)y0 * pitch + x);
+    for (int i = threadIdx.x; i < kT * kT * kB; i += blockDim.x) ys[i] = P[i].y;
+    ClaheAxis ax[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) ax[j] = clahe_axis(x + j, G);
+    __syncthreads();
+    if (!active) return;
+    for (int r = 0; r < kApplyRows; r++) {
+        const int y = y0 + r;
+        if (y >= N) break;
+        float4 nxt = v;
+        if (r + 1 < kApplyRows && y + 1 < N) nxt = *reinterpret_cast<const float4*>(in + (size_t)(y + 1) * pitch + x);   // next row, in flight during the lookups
+        const ClaheAxis ay = clahe_axis(y, G);
+        float4 c;
+        c.x = clahe_blend(ys, v.x, ax[0], ay);
+        c.y = clahe_blend(ys, v.y, ax[1], ay);
+        c.z = clahe_blend(ys, v.z, ax[2], ay);
+        c.w = clahe_blend(ys, v.w, ax[3], ay);
+        *reinterpret_cast<float4*>(out + (size_t)y * pitch + x) = c;
+        v = nxt;
+    }
+}
+
 void launch_clahe(hipStream_t st, const float* img, const float* relevant, float* out, const LevelDesc& l0, uint32_t* hist, musica_point* pts,
                   int batch) {
     hipLaunchKernelGGL(k_clahe_hist, dim3((l0.S + 7) / 8, 1, batch), dim3(256), 0, st, img, relevant, l0.S, l0.pitch, l0.plane, hist);
     hipLaunchKernelGGL(k_clahe_curve, dim3(kT * kT, batch), dim3(kB), 0, st, hist, pts);
-    hipLaunchKernelGGL(k_clahe_apply, dim3((l0.S + 31) / 32, (l0.S + 7) / 8, batch), dim3(32, 8), 0, st, img, out, l0.S, l0.pitch, l0.plane, pts);
+    if ((l0.S & 3) == 0)
+        hipLaunchKernelGGL(k_clahe_apply4, dim3((l0.S / 4 + 255) / 256, (l0.S + kApplyRows - 1) / kApplyRows, batch), dim3(256), 0, st, img, out, l0.S, l0.pitch, l0.plane, pts);
+    else
+        hipLaunchKernelGGL(k_clahe_apply, dim3((l0.S + 31) / 32, (l0.S + 7) / 8, batch), dim3(32, 8), 0, st, img, out, l0.S, l0.pitch, l0.plane, pts);
 }
 
 }  // namespace musica

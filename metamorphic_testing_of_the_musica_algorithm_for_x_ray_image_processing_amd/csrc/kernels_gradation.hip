@@ -193,6 +193,24 @@ __global__ void k_relevant(const float* __restrict__ normalized, const float* __
     out[o] = relevant_of(normalized[o], cc, (uint32_t)x, (uint32_t)y, (uint32_t)N);
 }
 
+// Four texels per thread (one 16-byte load / store) when the side and the cnr scale are multiples of 4: the four share a
+// cnr texel, its row index is the workgroup's (blockIdx.y = y). Same relevant_of() per texel.
+__global__ __launch_bounds__(256) void k_relevant4(const float* __restrict__ normalized, const float* __restrict__ cnr, float* __restrict__ out, int N, int pitch,
+                                                   size_t plane, int cnrS, int cnrPitch, size_t cnrPlane, int cnrScale) {
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (x >= N) return;
+    const size_t o = (size_t)blockIdx.z * plane + (size_t)y * pitch + x;
+    const float4 v = *reinterpret_cast<const float4*>(normalized + o);
+    const float cc = cnr_at(cnr + (size_t)blockIdx.z * cnrPlane, cnrS, cnrPitch, cnrScale, x, y);
+    float4 r;
+    r.x = relevant_of(v.x, cc, (uint32_t)x, (uint32_t)y, (uint32_t)N);
+    r.y = relevant_of(v.y, cc, (uint32_t)x + 1u, (uint32_t)y, (uint32_t)N);
+    r.z = relevant_of(v.z, cc, (uint32_t)x + 2u, (uint32_t)y, (uint32_t)N);
+    r.w = relevant_of(v.w, cc, (uint32_t)x + 3u, (uint32_t)y, (uint32_t)N);
+    *reinterpret_cast<float4*>(out + o) = r;
+}
+
 // ---- K12 + K20 ------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t* scratch /*[16]*/) {
 #pragma unroll
@@ -457,8 +475,12 @@ void launch_grad_hist_ref(hipStream_t st, const float* img, const float* relevan
 
 void launch_relevant(hipStream_t st, const float* normalized, const float* cnr, float* out, const LevelDesc& l0, const LevelDesc& l3,
                      int cnrScale, int batch) {
-    hipLaunchKernelGGL(k_relevant, dim3((l0.S + 31) / 32, (l0.S + 7) / 8, batch), dim3(32, 8), 0, st, normalized, cnr, out, l0.S, l0.pitch,
-                       l0.plane, l3.S, l3.pitch, l3.plane, cnrScale);
+    if ((l0.S & 3) == 0 && (cnrScale & 3) == 0 && cnrScale > 0)
+        hipLaunchKernelGGL(k_relevant4, dim3((l0.S / 4 + 255) / 256, l0.S, batch), dim3(256), 0, st, normalized, cnr, out, l0.S, l0.pitch,
+                           l0.plane, l3.S, l3.pitch, l3.plane, cnrScale);
+    else
+        hipLaunchKernelGGL(k_relevant, dim3((l0.S + 31) / 32, (l0.S + 7) / 8, batch), dim3(32, 8), 0, st, normalized, cnr, out, l0.S, l0.pitch,
+                           l0.plane, l3.S, l3.pitch, l3.plane, cnrScale);
 }
 
 void launch_grad_curve(hipStream_t st, uint32_t* hist, musica_hist_max_point* gmax, DevCurve* curves, int batch, const uint32_t* hist_b, const uint32_t* gzero) {
