@@ -194,14 +194,29 @@ __global__ void k_relevant(const float* __restrict__ normalized, const float* __
 }
 
 // Four texels per thread (one 16-byte load / store) when the side and the cnr scale are multiples of 4: the four share a
-// cnr texel, its row index is the workgroup's (blockIdx.y = y). Same relevant_of() per texel.
-__global__ __launch_bounds__(256) void k_relevant4(const float* __restrict__ normalized, const float* __restrict__ cnr, float* __restrict__ out, int N, int pitch,
+// cnr texel, its row index is the workgroup's (blockIdx.y = y). Same relevant_of() per texel. RAW: `normalized <= 0.9` is
+// tested as raw <= thr090[image] (norm_threshold_090: exact, the normalisation is monotone) on the raw uint16 pixels, so a
+// context that normalises on the fly needs no stored normalized image for its CLAHE block either.
+template <bool RAW>
+__global__ __launch_bounds__(256) void k_relevant4(const float* __restrict__ normalized, const uint16_t* __restrict__ raw, const int* __restrict__ thr090,
+                                                   const float* __restrict__ cnr, float* __restrict__ out, int N, int pitch,
                                                    size_t plane, int cnrS, int cnrPitch, size_t cnrPlane, int cnrScale) {
     const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int y = blockIdx.y;
     if (x >= N) return;
     const size_t o = (size_t)blockIdx.z * plane + (size_t)y * pitch + x;
-    const float4 v = *reinterpret_cast<const float4*>(normalized + o);
+    float4 v;
+    if (RAW) {
+        const uint2 q = *reinterpret_cast<const uint2*>(raw + ((size_t)blockIdx.z * N + y) * N + x);
+        const int thr = thr090[blockIdx.z];
+        // stand-ins with the same truth value of `pixel <= 0.90f`
+        v.x = (int)(q.x & 0xFFFFu) <= thr ? 0.0f : 1.0f;
+        v.y = (int)(q.x >> 16) <= thr ? 0.0f : 1.0f;
+        v.z = (int)(q.y & 0xFFFFu) <= thr ? 0.0f : 1.0f;
+        v.w = (int)(q.y >> 16) <= thr ? 0.0f : 1.0f;
+    } else {
+        v = *reinterpret_cast<const float4*>(normalized + o);
+    }
     const float cc = cnr_at(cnr + (size_t)blockIdx.z * cnrPlane, cnrS, cnrPitch, cnrScale, x, y);
     float4 r;
     r.x = relevant_of(v.x, cc, (uint32_t)x, (uint32_t)y, (uint32_t)N);
@@ -474,10 +489,13 @@ void launch_grad_hist_ref(hipStream_t st, const float* img, const float* relevan
 }
 
 void launch_relevant(hipStream_t st, const float* normalized, const float* cnr, float* out, const LevelDesc& l0, const LevelDesc& l3,
-                     int cnrScale, int batch) {
-    if ((l0.S & 3) == 0 && (cnrScale & 3) == 0 && cnrScale > 0)
-        hipLaunchKernelGGL(k_relevant4, dim3((l0.S / 4 + 255) / 256, l0.S, batch), dim3(256), 0, st, normalized, cnr, out, l0.S, l0.pitch,
-                           l0.plane, l3.S, l3.pitch, l3.plane, cnrScale);
+                     int cnrScale, int batch, const uint16_t* raw, const int* thr090) {
+    const bool vec = (l0.S & 3) == 0 && (cnrScale & 3) == 0 && cnrScale > 0;
+    const dim3 grid4((l0.S / 4 + 255) / 256, l0.S, batch);
+    if (vec && raw && thr090)
+        hipLaunchKernelGGL(k_relevant4<true>, grid4, dim3(256), 0, st, normalized, raw, thr090, cnr, out, l0.S, l0.pitch, l0.plane, l3.S, l3.pitch, l3.plane, cnrScale);
+    else if (vec)
+        hipLaunchKernelGGL(k_relevant4<false>, grid4, dim3(256), 0, st, normalized, raw, thr090, cnr, out, l0.S, l0.pitch, l0.plane, l3.S, l3.pitch, l3.plane, cnrScale);
     else
         hipLaunchKernelGGL(k_relevant, dim3((l0.S + 31) / 32, (l0.S + 7) / 8, batch), dim3(32, 8), 0, st, normalized, cnr, out, l0.S, l0.pitch,
                            l0.plane, l3.S, l3.pitch, l3.plane, cnrScale);

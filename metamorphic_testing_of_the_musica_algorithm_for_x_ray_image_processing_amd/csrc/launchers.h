@@ -90,7 +90,8 @@ void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const u
 // kernels_gradation.hip
 void launch_grad_hist(hipStream_t st, const GradArgs& a, int batch);
 void launch_grad_hist_ref(hipStream_t st, const float* img, const float* relevant, const LevelDesc& l0, uint32_t* hist, int batch);
-void launch_relevant(hipStream_t st, const float* normalized, const float* cnr, float* out, const LevelDesc& l0, const LevelDesc& l3, int cnrScale, int batch);
+void launch_relevant(hipStream_t st, const float* normalized, const float* cnr, float* out, const LevelDesc& l0, const LevelDesc& l3,
+                     int cnrScale, int batch, const uint16_t* raw = nullptr, const int* thr090 = nullptr);
 void launch_grad_curve(hipStream_t st, uint32_t* hist, musica_hist_max_point* gmax, DevCurve* curves, int batch, const uint32_t* hist_b = nullptr, const uint32_t* gzero = nullptr);
 void launch_grad_apply(hipStream_t st, const float* in, float* out, const LevelDesc& l0, const DevCurve* curves, int batch);
 // kernels_bench.hip (measurement aid)

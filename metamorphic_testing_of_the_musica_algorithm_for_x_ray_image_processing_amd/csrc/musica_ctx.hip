@@ -68,6 +68,7 @@ struct musica_ctx {
     hipStream_t side1;       // dag == 1: sdev 2 beside the coarse chain
     hipEvent_t ev_s1, ev_s2;
     bool fuse_u16;           // level-0 kernels read the raw uint16 pixels; the normalized image is produced on demand only
+    bool clahe_raw;          // CLAHE context whose relevant image is computed from the raw pixels (no stored normalized image)
     bool norm_valid;         // d_norm holds the normalized image of the current input
     // hipGraph replay of the two-stream dispatch (captured once per input pointer; MUSICA_FLAG_NO_GRAPH /
     // MUSICA_GRAPH=0 / per-kernel profiling fall back to eager launches)
@@ -435,7 +436,10 @@ static musica_ctx* create_impl(const musica_params* params) {
     if (!c->fuse_u16 && c->fuse_rb == 1) c->fuse_rb = 0;
     // fused gradation histogram: streaming level-0 kernels on raw pixels, cnr scale 8 (every N >= 57 with N % 8 == 0), no CLAHE
     // block (it wants the stored relevant image anyway)
-    c->fuse_gh = env_int("MUSICA_FUSE_GH", 1) != 0 && c->fuse_u16 && !(params->flags & MUSICA_FLAG_CLAHE) &&
+    // (a CLAHE context fuses too since its relevant image comes from the raw pixels, k_relevant4<true>; MUSICA_CLAHE_FUSE=0: as before)
+    c->clahe_raw = (params->flags & MUSICA_FLAG_CLAHE) && c->fuse_u16 && (N % 4) == 0 && env_int("MUSICA_CLAHE_FUSE", 1) != 0 &&
+                   (cnr_scale(c->lv[0].S, c->lv[MUSICA_CNR_LEVEL].S) % 4) == 0;
+    c->fuse_gh = env_int("MUSICA_FUSE_GH", 1) != 0 && c->fuse_u16 && (!(params->flags & MUSICA_FLAG_CLAHE) || c->clahe_raw) &&
                  cnr_scale(c->lv[0].S, c->lv[MUSICA_CNR_LEVEL].S) == 8;
     ok = ok && dalloc(c, &c->d_input, B * N * N);
     ok = ok && dalloc(c, &c->d_minmax, B * kMinMaxStride);
@@ -564,7 +568,7 @@ static const float* level_input(musica_ctx* c, int i) { return i == 0 ? c->d_nor
 static void enqueue_norm(musica_ctx* c) {
     { Span sp(c, MUSICA_KERNEL_MINMAX); launch_minmax(c->stream, c->cur_input, c->N, c->d_minmax, c->B); }
     c->norm_valid = false;
-    if (!c->fuse_u16 || c->d_clahe_hist) {  // the CLAHE block reads the stored normalized image through k_relevant
+    if (!c->fuse_u16 || (c->d_clahe_hist && !c->clahe_raw)) {  // a CLAHE block that reads the stored normalized image through k_relevant
         Span sp(c, MUSICA_KERNEL_NORMALIZE);
         launch_normalize(c->stream, c->cur_input, c->d_norm, c->lv[0], c->d_minmax, c->min_chain_exact, c->B);
         c->norm_valid = true;
@@ -691,7 +695,8 @@ static void enqueue_gradation(musica_ctx* c, bool fused) {
     const LevelDesc& l3 = c->lv[MUSICA_CNR_LEVEL];
     const int scale = (int)cnr_scale(l0.S, l3.S);
     if (c->d_clahe_hist) {  // #ifdef ENABLE_CLAHE block, src/vk_processing.cpp:2471-2489
-        launch_relevant(c->stream, c->d_norm, c->d_cnr, c->d_scratch, l0, l3, scale, c->B);
+        if (c->clahe_raw) launch_relevant(c->stream, c->d_norm, c->d_cnr, c->d_scratch, l0, l3, scale, c->B, c->cur_input, c->d_thr090);
+        else launch_relevant(c->stream, c->d_norm, c->d_cnr, c->d_scratch, l0, l3, scale, c->B);
         launch_clahe(c->stream, c->d_recon[0], c->d_scratch, c->d_clahe_graded, l0, c->d_clahe_hist, c->d_clahe_pts, c->B);
     }
     {
@@ -853,7 +858,7 @@ static int enqueue_all(musica_ctx* c) {
         }
         if (k >= 0) {
             c->graph_next = k ^ 1;                         // the other slot is now the least recently used
-            c->norm_valid = c->d_clahe_hist != nullptr || !c->fuse_u16;
+            c->norm_valid = (c->d_clahe_hist != nullptr && !c->clahe_raw) || !c->fuse_u16;
             if (hipGraphLaunch(c->graph_exec[k], c->stream) != hipSuccess) return fail("hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError()));
             return 1;
         }

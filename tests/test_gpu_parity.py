@@ -640,3 +640,24 @@ def test_steps_in_flight_on_three_contexts_are_the_lone_contexts_steps(ob):
             o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[c][k])
             _compare_all(pipe.contexts[c], o, ob, idx=k, tag="context %d image %d: " % (c, k))
     pipe.cleanup()
+
+
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_clahe_context_with_and_without_the_raw_pixel_relevant_image(ob, fuse, monkeypatch):
+    """A CLAHE context normally takes `normalized <= 0.9` of its relevant image from the raw pixels (no stored normalized image,
+    gradation histogram inside the level-0 expand launch); MUSICA_CLAHE_FUSE=0 is the stored-image form. Both equal the oracle
+    bit for bit, including the CLAHE histograms, curves and the blended image."""
+    monkeypatch.setenv("MUSICA_CLAHE_FUSE", fuse)
+    n, levels = 1024, 6
+    px = phantom(n, 77)
+    o = ob.Oracle(n, levels, ob.ORDER_FAST, ob.FLAG_CLAHE).execute(px)
+    p = _proc(n, levels, flags=mp.FLAG_CLAHE)
+    assert p.fuses_gradhist() == (fuse == "1")
+    for rep in range(2):
+        assert p.execute(px), mp.last_error()
+    _compare_all(p, o, ob, tag="clahe fuse=%s: " % fuse)
+    assert np.array_equal(p.clahe_hist(), o.clahe_hist())
+    a, b = p.clahe_curves(), o.clahe_curves()
+    assert ((a == b) | (np.isnan(a) & np.isnan(b))).all()
+    _same(p.image(mp.IMG_CLAHE_GRADED), o.image(ob.IMG_CLAHE_GRADED), "clahe graded")
+    p.cleanup()
