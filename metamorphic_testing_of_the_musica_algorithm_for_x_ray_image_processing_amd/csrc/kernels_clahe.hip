@@ -16,21 +16,38 @@ constexpr int kB = MUSICA_CLAHE_BINS;
 // K22 clahe_histogram.comp:13-45 — hist[tx][ty][bin] += 1 where relevant == 1.0.
 // One workgroup per band of 8 consecutive rows (a band touches one or two tile rows, so its flush is short; the
 // LDS copy still holds all 16 tiles), 4 columns per thread with 16-byte loads.
+// RAWREL: the relevant value is computed here (relevant_of() on the cnr texel and `raw <= thr090` standing for
+// `normalized <= 0.9`, as in k_relevant4<true>) instead of read from a stored relevant image: 6 B/px instead of 8, and the
+// context's hot path writes no relevant image at all (musica_get_image computes it on demand). N % 4 == 0.
+template <bool RAWREL>
 __global__ __launch_bounds__(256) void k_clahe_hist(const float* __restrict__ img, const float* __restrict__ relevant, int N, int pitch,
-                                                    size_t plane, uint32_t* __restrict__ hist) {
+                                                    size_t plane, uint32_t* __restrict__ hist, const uint16_t* __restrict__ raw,
+                                                    const int* __restrict__ thr090, const float* __restrict__ cnr, int cnrS, int cnrPitch,
+                                                    size_t cnrPlane, int cnrScale) {
     __shared__ uint32_t lh[kT * kT * kB];
     for (int i = threadIdx.x; i < kT * kT * kB; i += blockDim.x) lh[i] = 0u;
     __syncthreads();
     img += (size_t)blockIdx.z * plane;
-    relevant += (size_t)blockIdx.z * plane;
+    if (!RAWREL) relevant += (size_t)blockIdx.z * plane;
+    const int thr = RAWREL ? thr090[blockIdx.z] : 0;
     const float fN = (float)N;
     for (int y = blockIdx.x * 8; y < min(blockIdx.x * 8 + 8, N); y++) {
         const uint32_t ty = f2u((float)y / fN * (float)kT);                      // :35
         const float* irow = img + (size_t)y * pitch;
-        const float* rrow = relevant + (size_t)y * pitch;
         for (int x0 = threadIdx.x * 4; x0 < N; x0 += blockDim.x * 4) {
-            const float4 c4 = load4_guard(irow, x0, N), r4 = load4_guard(rrow, x0, N);
-            const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+            const float4 c4 = load4_guard(irow, x0, N);
+            float rv[4];
+            if (RAWREL) {
+                const uint2 q = *reinterpret_cast<const uint2*>(raw + ((size_t)blockIdx.z * N + y) * N + x0);
+                const float cc = cnr_at(cnr + (size_t)blockIdx.z * cnrPlane, cnrS, cnrPitch, cnrScale, x0, y);   // one texel for the four (scale % 4 == 0)
+                const int pxl[4] = {(int)(q.x & 0xFFFFu), (int)(q.x >> 16), (int)(q.y & 0xFFFFu), (int)(q.y >> 16)};
+#pragma unroll
+                for (int j = 0; j < 4; j++) rv[j] = relevant_of(pxl[j] <= thr ? 0.0f : 1.0f, cc, (uint32_t)(x0 + j), (uint32_t)y, (uint32_t)N);
+            } else {
+                const float4 r4 = load4_guard(relevant + (size_t)y * pitch, x0, N);
+                rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
+            }
+            const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int x = x0 + j;
@@ -258,8 +275,13 @@ __global__ __launch_bounds__(256) void k_clahe_apply4(const float* __restrict__ 
 }
 
 void launch_clahe(hipStream_t st, const float* img, const float* relevant, float* out, const LevelDesc& l0, uint32_t* hist, musica_point* pts,
-                  int batch) {
-    hipLaunchKernelGGL(k_clahe_hist, dim3((l0.S + 7) / 8, 1, batch), dim3(256), 0, st, img, relevant, l0.S, l0.pitch, l0.plane, hist);
+                  int batch, const uint16_t* raw, const int* thr090, const float* cnr, const LevelDesc* l3, int cnrScale) {
+    const dim3 hgrid((l0.S + 7) / 8, 1, batch);
+    if (raw && thr090 && cnr && l3 && (l0.S & 3) == 0 && cnrScale > 0 && (cnrScale & 3) == 0)   // relevant image computed on the fly
+        hipLaunchKernelGGL(k_clahe_hist<true>, hgrid, dim3(256), 0, st, img, relevant, l0.S, l0.pitch, l0.plane, hist, raw, thr090, cnr, l3->S, l3->pitch,
+                           l3->plane, cnrScale);
+    else
+        hipLaunchKernelGGL(k_clahe_hist<false>, hgrid, dim3(256), 0, st, img, relevant, l0.S, l0.pitch, l0.plane, hist, raw, thr090, cnr, 0, 0, (size_t)0, 0);
     hipLaunchKernelGGL(k_clahe_curve, dim3(kT * kT, batch), dim3(kB), 0, st, hist, pts);
     if ((l0.S & 3) == 0)
         hipLaunchKernelGGL(k_clahe_apply4, dim3((l0.S / 4 + 255) / 256, (l0.S + kApplyRows - 1) / kApplyRows, batch), dim3(256), 0, st, img, out, l0.S, l0.pitch, l0.plane, pts);

@@ -318,4 +318,23 @@ __device__ __forceinline__ void curve_store_parallel(DevCurve* c, const float* s
     }
 }
 
+// img_relevant.comp:28-64. `c` is cnr * 256 already. pow(r, 5.0) is restated as ((r*r)*(r*r))*r (oracle Q5).
+__device__ __forceinline__ float relevant_of(float pixel, float c, uint32_t x, uint32_t y, uint32_t N) {
+    const uint32_t border = 100u, lim = N - border;  // uint arithmetic as in the shader (wraps for N < 100)
+    const bool inside = x > border && x < lim && y > border && y < lim;
+    if (!inside) return 0.0f;
+    if (c >= 1.0f && c <= 6.0f) {
+        const float r = c / 6.0f;
+        return ((r * r) * (r * r)) * r;
+    }
+    if (c >= 6.0f && c <= kMaxCnrValue && pixel <= 0.90f) return 1.0f;
+    return 0.0f;
+}
+
+__device__ __forceinline__ float cnr_at(const float* __restrict__ cnr, int cnrS, int cnrPitch, int scale, int x, int y) {
+    const int cx = x / scale, cy = y / scale;
+    return ((cx < cnrS && cy < cnrS) ? cnr[(size_t)cy * cnrPitch + cx] : 0.0f) * kMaxCnrValue;
+}
+
+
 }  // namespace musica

@@ -10,24 +10,6 @@
 
 namespace musica {
 
-// img_relevant.comp:28-64. `c` is cnr * 256 already. pow(r, 5.0) is restated as ((r*r)*(r*r))*r (oracle Q5).
-__device__ __forceinline__ float relevant_of(float pixel, float c, uint32_t x, uint32_t y, uint32_t N) {
-    const uint32_t border = 100u, lim = N - border;  // uint arithmetic as in the shader (wraps for N < 100)
-    const bool inside = x > border && x < lim && y > border && y < lim;
-    if (!inside) return 0.0f;
-    if (c >= 1.0f && c <= 6.0f) {
-        const float r = c / 6.0f;
-        return ((r * r) * (r * r)) * r;
-    }
-    if (c >= 6.0f && c <= kMaxCnrValue && pixel <= 0.90f) return 1.0f;
-    return 0.0f;
-}
-
-__device__ __forceinline__ float cnr_at(const float* __restrict__ cnr, int cnrS, int cnrPitch, int scale, int x, int y) {
-    const int cx = x / scale, cy = y / scale;
-    return ((cx < cnrS && cy < cnrS) ? cnr[(size_t)cy * cnrPitch + cx] : 0.0f) * kMaxCnrValue;
-}
-
 // gradation_histogram.comp:14-34 — the reference's thread (gx, gy) walks its 16x16 area column
 // by column (m = x outer, n = y inner) and `return`s at the first pixel that is exactly 0, so a
 // pixel at scan position m*16+n counts iff it precedes the area's first zero. Here a lane owns 4

@@ -97,6 +97,7 @@ void launch_grad_apply(hipStream_t st, const float* in, float* out, const LevelD
 // kernels_bench.hip (measurement aid)
 void launch_copy41(hipStream_t st, const float* in, float* out, int side);
 // kernels_clahe.hip
-void launch_clahe(hipStream_t st, const float* img, const float* relevant, float* out, const LevelDesc& l0, uint32_t* hist, musica_point* pts, int batch);
+void launch_clahe(hipStream_t st, const float* img, const float* relevant, float* out, const LevelDesc& l0, uint32_t* hist, musica_point* pts, int batch,
+                  const uint16_t* raw = nullptr, const int* thr090 = nullptr, const float* cnr = nullptr, const LevelDesc* l3 = nullptr, int cnrScale = 0);
 
 }  // namespace musica

@@ -695,9 +695,12 @@ static void enqueue_gradation(musica_ctx* c, bool fused) {
     const LevelDesc& l3 = c->lv[MUSICA_CNR_LEVEL];
     const int scale = (int)cnr_scale(l0.S, l3.S);
     if (c->d_clahe_hist) {  // #ifdef ENABLE_CLAHE block, src/vk_processing.cpp:2471-2489
-        if (c->clahe_raw) launch_relevant(c->stream, c->d_norm, c->d_cnr, c->d_scratch, l0, l3, scale, c->B, c->cur_input, c->d_thr090);
-        else launch_relevant(c->stream, c->d_norm, c->d_cnr, c->d_scratch, l0, l3, scale, c->B);
-        launch_clahe(c->stream, c->d_recon[0], c->d_scratch, c->d_clahe_graded, l0, c->d_clahe_hist, c->d_clahe_pts, c->B);
+        if (c->clahe_raw) {   // relevance computed inside the histogram launch from the raw pixels: no relevant image on the hot path
+            launch_clahe(c->stream, c->d_recon[0], nullptr, c->d_clahe_graded, l0, c->d_clahe_hist, c->d_clahe_pts, c->B, c->cur_input, c->d_thr090, c->d_cnr, &l3, scale);
+        } else {
+            launch_relevant(c->stream, c->d_norm, c->d_cnr, c->d_scratch, l0, l3, scale, c->B);
+            launch_clahe(c->stream, c->d_recon[0], c->d_scratch, c->d_clahe_graded, l0, c->d_clahe_hist, c->d_clahe_pts, c->B);
+        }
     }
     {
         Span sp(c, MUSICA_KERNEL_GRAD_HIST);
