@@ -189,7 +189,7 @@ __global__ void k_sqrt(const uint16_t* __restrict__ px, float* __restrict__ out,
 template <bool HIST, bool A8>
 __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
                                                                 size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov,
-                                                                int rows_per_wave) {
+                                                                int rows_per_wave, int swz) {
     __shared__ uint32_t lh[kHistLdsWords];
     hist_lds_clear(lh);
     __syncthreads();
@@ -198,9 +198,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __r
     sdev += (size_t)img * plane;
     const Buf db = make_buf(sdev, plane * 4);
     const int lane = threadIdx.x & 63;
-    const int seg = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
+    const Tile tile = xcd_tile(swz);
+    const int seg = __builtin_amdgcn_readfirstlane((int)(tile.segblock * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
     const int y0 = seg * rows_per_wave;
-    const SCfg g = make_scfg(blockIdx.x, lane, S);
+    const SCfg g = make_scfg(tile.strip, lane, S);
     const uint32_t rb = (uint32_t)pitch * 4u;
     auto roff = [&](int row) -> uint32_t { return (row >= 0 && row < S) ? (uint32_t)row * rb : kOob; };
     if (y0 < S) {
@@ -556,8 +557,8 @@ void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const Leve
     const int strips = (l.S + kStripCols - 1) / kStripCols;
     const int segs = (l.S + rows_per_wave - 1) / rows_per_wave;
     const dim3 grid(strips, (segs + kWavesPerBlock - 1) / kWavesPerBlock, batch);
-    if ((l.S & 7) == 0) hipLaunchKernelGGL((k_sdev_hist_pf<true, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
-    else hipLaunchKernelGGL((k_sdev_hist_pf<true, false>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave);
+    if ((l.S & 7) == 0) hipLaunchKernelGGL((k_sdev_hist_pf<true, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave, xcd_swizzle_on());
+    else hipLaunchKernelGGL((k_sdev_hist_pf<true, false>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave, xcd_swizzle_on());
 }
 
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch) {

@@ -71,6 +71,26 @@ __device__ __forceinline__ void bstore4(const Buf& b, uint32_t off, float4 v) {
     llvm_buffer_store_v4f32(u, b.r, (int)off, 0, 0);
 }
 
+// ---- which tile a workgroup works on ----
+// The hardware hands workgroups to the 8 XCDs round-robin by linear workgroup id, and every XCD has an L2 of its own: with the
+// plain (blockIdx.x = strip, blockIdx.y = block of segments) mapping, the strips left and right of a strip and — unless the grid
+// is 8 wide — the segments above and below it belong to other XCDs, so the halo lines two neighbours both read are fetched
+// once per XCD. With swz the workgroups of XCD k take the k-th eighth of the segment blocks, strip by strip: neighbours in
+// both directions share one L2 (and are dispatched back to back). Needs gridDim.y % 8 == 0 (else the plain mapping).
+struct Tile { int strip, segblock; };
+__device__ __forceinline__ Tile xcd_tile(int swz) {
+    Tile t;
+    t.strip = (int)blockIdx.x; t.segblock = (int)blockIdx.y;
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    if (swz && (gy & 7u) == 0u) {
+        const unsigned lin = blockIdx.x + gx * blockIdx.y;
+        const unsigned xcd = lin & 7u, j = lin >> 3;
+        t.strip = (int)(j % gx);
+        t.segblock = (int)(xcd * (gy >> 3) + j / gx);
+    }
+    return t;
+}
+
 // ---- arithmetic in the oracle's MUSICA_ORDER_FAST order ----
 // ((((w0*a + w1*b) + w2*c) + w3*d) + w4*e), products and sums rounded separately.
 __device__ __forceinline__ float chain5(float a, float b, float c, float d, float e) {

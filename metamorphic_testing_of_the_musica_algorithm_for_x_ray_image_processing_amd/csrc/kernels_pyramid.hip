@@ -125,15 +125,16 @@ __device__ __forceinline__ void reduce_row(const RowR& r0, const RowR& r1, const
 template <int D, int TAG>
 __global__ __launch_bounds__(kBlockThreads) void k_reduce_fast_pf(const float* __restrict__ in, float* __restrict__ out,
                                                                   int S, int pitch, size_t in_plane, int So, int opitch,
-                                                                  size_t out_plane, int rows_per_wave) {
+                                                                  size_t out_plane, int rows_per_wave, int swz) {
     const int lane = threadIdx.x & 63;
-    const int seg = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
+    const Tile tile = xcd_tile(swz);
+    const int seg = __builtin_amdgcn_readfirstlane((int)(tile.segblock * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
     const int yo0 = seg * rows_per_wave;
     if (yo0 >= So) return;  // wave-uniform
     const int yo1 = min(yo0 + rows_per_wave, So);
     const Buf ib = make_buf(in + (size_t)blockIdx.z * in_plane, in_plane * 4);
     const Buf ob = make_buf(out + (size_t)blockIdx.z * out_plane, out_plane * 4);
-    const LaneCfg g = make_cfg(blockIdx.x, lane, S);
+    const LaneCfg g = make_cfg(tile.strip, lane, S);
     const int hi = S - 1;
     const uint32_t rb = (uint32_t)pitch * 4u, orb = (uint32_t)opitch * 4u;
     // Odd segments march upwards, even ones downwards: two vertically adjacent wavefronts then touch
@@ -516,9 +517,10 @@ template <bool U16>
 __global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __restrict__ fine, float* __restrict__ down, float* __restrict__ band,
                                                                int S, int pitch, size_t plane, int Sc, int cpitch, size_t cplane,
                                                                int rows_per_wave, const uint32_t* __restrict__ minmax, int min_chain_exact,
-                                                               uint16_t* __restrict__ le090) {
+                                                               uint16_t* __restrict__ le090, int swz) {
     const int lane = threadIdx.x & 63;
-    const int seg = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
+    const Tile tile = xcd_tile(swz);
+    const int seg = __builtin_amdgcn_readfirstlane((int)(tile.segblock * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
     const int k0 = seg * rows_per_wave;
     if (k0 >= Sc) return;  // wave-uniform
     const int k1 = min(k0 + rows_per_wave, Sc);
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __
                        : make_buf(reinterpret_cast<const float*>(fine) + (size_t)img * plane, plane * 4);
     const Buf db = make_buf(down + (size_t)img * cplane, cplane * 4);
     const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
-    const LaneCfg g = make_cfg(blockIdx.x, lane, S);
+    const LaneCfg g = make_cfg(tile.strip, lane, S);
     // U16 with le090: one uint16 per lane and row pair, bit j / 8 + j = `normalized <= 0.9` (img_relevant.comp:58) of column c + j in the
     // even / odd row — the level-0 expand launch bins the gradation histogram with it instead of reading the raw pixels again
     const bool want_mask = U16 && le090 != nullptr;
@@ -725,7 +727,8 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
     // slope of noise_reduction.comp:28, the same value for every texel
     const float nr_m = (a.highFactor - a.lowFactor) / (a.highCnr - a.lowCnr);
     const int lane = threadIdx.x & 63;
-    const int seg = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
+    const Tile tile = xcd_tile(a.swz);
+    const int seg = __builtin_amdgcn_readfirstlane((int)(tile.segblock * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
     const int k0 = seg * a.rows_per_wave;
     bool saw_zero = false;
     if (k0 < a.Sc) {   // wave-uniform
@@ -738,7 +741,7 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
     const Buf pb = make_buf(a.prev + (size_t)img * a.cplane, a.cplane * 4);
     const Buf wb = !GH ? bb : MASK ? make_buf(a.le090 + (size_t)img * a.Sc * (S / 8), (size_t)a.Sc * (S / 8) * 2) : make_buf(a.raw + (size_t)img * S * S, (size_t)S * S * 2);
     const float* cnr = NR ? a.cnr + (size_t)img * a.cnrPlane : nullptr;
-    const LaneCfg g = make_cfg(blockIdx.x, lane, S);
+    const LaneCfg g = make_cfg(tile.strip, lane, S);
     const uint32_t rb = (uint32_t)a.pitch * 4u, crb = (uint32_t)a.cpitch * 4u;
     const uint32_t moff = g.off == kOob ? kOob : (uint32_t)g.c >> 2, mrb = (uint32_t)S >> 2;
     const uint32_t urb = (uint32_t)S * 2u, uoff = g.off == kOob ? kOob : g.off >> 1;
@@ -950,6 +953,11 @@ __global__ void k_exp_band_generic(ExpandArgs a) {
 // host-side launchers
 // ======================================================================================
 
+int xcd_swizzle_on() {
+    static const int on = getenv("MUSICA_XCD_SWIZZLE") ? atoi(getenv("MUSICA_XCD_SWIZZLE")) : 1;
+    return on;
+}
+
 static inline dim3 stream_grid(int S, int rows, int rows_per_wave, int batch) {
     const int strips = (S + kStripCols - 1) / kStripCols;
     const int segs = (rows + rows_per_wave - 1) / rows_per_wave;
@@ -966,7 +974,7 @@ void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* 
     if (fast_ok(li.S) && !force_generic) {
         const dim3 grid = stream_grid(li.S, lo.S, rows_per_wave, batch);
         auto* kern = tag == 0 ? k_reduce_fast_pf<1, 0> : tag == 1 ? k_reduce_fast_pf<1, 1> : tag == 2 ? k_reduce_fast_pf<1, 2> : tag == 3 ? k_reduce_fast_pf<1, 3> : k_reduce_fast_pf<1, 4>;
-        hipLaunchKernelGGL(kern, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave);
+        hipLaunchKernelGGL(kern, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave, xcd_swizzle_on());
     } else {
         hipLaunchKernelGGL(k_reduce_generic, generic_grid(lo.S, batch), kGenericBlock, 0, st, in, out, li.S, li.pitch,
                            li.plane, lo.S, lo.pitch, lo.plane);
@@ -982,12 +990,12 @@ void launch_reduce_u16(hipStream_t st, const uint16_t* px, const LevelDesc& li, 
 void launch_reduce_band_u16(hipStream_t st, const uint16_t* px, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                             int rows_per_wave, const uint32_t* minmax, int min_chain_exact, uint16_t* le090) {
     hipLaunchKernelGGL(k_reduce_band<true>, stream_grid(lf.S, lc.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, (const void*)px, down, band, lf.S,
-                       lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact, le090);
+                       lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact, le090, xcd_swizzle_on());
 }
 // levels >= 1 (f32 fine image); the side must be a multiple of 8 and at least 16 (the caller checks)
 void launch_reduce_band(hipStream_t st, const float* fine, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave) {
     hipLaunchKernelGGL(k_reduce_band<false>, stream_grid(lf.S, lc.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, (const void*)fine, down, band, lf.S,
-                       lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, (const uint32_t*)nullptr, 0, (uint16_t*)nullptr);
+                       lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, (const uint32_t*)nullptr, 0, (uint16_t*)nullptr, xcd_swizzle_on());
 }
 void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                      int rows_per_wave, int rows_per_trip, const uint32_t* minmax, int min_chain_exact) {

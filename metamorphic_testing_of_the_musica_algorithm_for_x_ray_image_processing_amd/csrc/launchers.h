@@ -39,6 +39,7 @@ struct ExpandArgs {
     uint32_t* gzero;         // [batch]: set when a reconstructed texel is exactly 0 (the `return` of gradation_histogram.comp:24
                              // then cuts the scan of its 16 x 16 area short: k_grad_hist redoes that image literally)
     const uint16_t* le090;   // or: [batch][Sc][S / 8] bits of `normalized <= 0.9` written by launch_reduce_band_u16 (then raw / thr090 are not read)
+    int swz;                 // XCD-aware tile mapping (kernels_common.h xcd_tile)
     const int* thr090;       // [batch]: largest raw value whose normalized value is <= 0.9 (k_curves_cnr)
 };
 
@@ -84,6 +85,8 @@ void launch_curves_cnr(hipStream_t st, const uint32_t* hist, size_t hist_stride,
 void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& l3, const musica_hist_max_point* maxpts, int levels, int batch);
 void launch_selftest_exact_math(hipStream_t st, unsigned long long* d_bad4);
 constexpr int kStatsMaxBlocks = 64;
+// XCD-aware workgroup -> tile mapping of the marching kernels (kernels_common.h xcd_tile); MUSICA_XCD_SWIZZLE=0 turns it off
+int xcd_swizzle_on();
 void launch_stats(hipStream_t st, const float* cnr, const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact,
                   const musica_hist_max_point* noise_max, int levels, const musica_hist_max_point* grad_max, const DevCurve* gcurve,
                   musica_stats* out, uint32_t image_id_base, uint32_t image_id_stride, int batch, double* partial);

@@ -661,6 +661,7 @@ static ExpandArgs expand_args(musica_ctx* c, int lvl, float* dst) {
     a.lowCnr = q.lowCnr; a.lowFactor = q.lowFactor; a.highCnr = q.highCnr; a.highFactor = q.highFactor;
     a.rows_per_wave = c->rows_expand[lvl];
     a.raw = nullptr; a.ghist = nullptr; a.gzero = nullptr; a.thr090 = nullptr; a.le090 = nullptr;
+    a.swz = xcd_swizzle_on();
     return a;
 }
 static int gain_mode(int lvl) { return lvl > MUSICA_CNR_LEVEL ? GAIN_CONST : (lvl == MUSICA_CNR_LEVEL ? GAIN_RANGE : GAIN_CURVE); }

@@ -185,7 +185,7 @@ def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
             p.cleanup()
 
 
-@pytest.mark.parametrize("env", [{"MUSICA_BAND_TRIP": "1"}, {"MUSICA_EXPAND_TRIP": "2"}, {"MUSICA_U16": "0"}, {"MUSICA_FUSE_GH": "0"}, {"MUSICA_GH_OCC": "3"}, {"MUSICA_FUSE_RB": "0"}, {"MUSICA_FUSE_RB": "1"}, {"MUSICA_LE090": "0"}, {"MUSICA_GH_OCC": "3", "MUSICA_LE090": "1"},
+@pytest.mark.parametrize("env", [{"MUSICA_BAND_TRIP": "1"}, {"MUSICA_EXPAND_TRIP": "2"}, {"MUSICA_U16": "0"}, {"MUSICA_FUSE_GH": "0"}, {"MUSICA_GH_OCC": "3"}, {"MUSICA_FUSE_RB": "0"}, {"MUSICA_FUSE_RB": "1"}, {"MUSICA_LE090": "0"}, {"MUSICA_GH_OCC": "3", "MUSICA_LE090": "1"}, {"MUSICA_XCD_SWIZZLE": "0"},
                                  {"MUSICA_FUSE_RB": "2", "MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "4"}, {"MUSICA_FUSE_RB": "2", "MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "64"},
                                  {"MUSICA_FUSE_GH": "1", "MUSICA_EXPAND_TRIP": "2"},
                                  {"MUSICA_AUTOTUNE": "0", "MUSICA_REDUCE_ROWS": "4", "MUSICA_BAND_ROWS": "2", "MUSICA_EXPAND_ROWS": "2", "MUSICA_SDEV_ROWS": "16"},
