@@ -927,7 +927,7 @@ static void autotune(musica_ctx* c) {
             {&c->rows_reduce[i], cand_reduce, 5, run_reduce_level, !rb_level(c, i)},
             {&c->rows_band[i], cand_pair, 4, run_band_level, !rb_level(c, i)},
             {&c->rows_expand[i], cand_pair, 4, run_expand_level, true},
-            {i <= MUSICA_CNR_LEVEL ? &c->rows_sdev[i] : nullptr, cand_sdev, 3, run_sdev_level, i <= MUSICA_CNR_LEVEL},
+            {i <= MUSICA_CNR_LEVEL ? &c->rows_sdev[i] : nullptr, cand_sdev, 3, run_sdev_level, i <= MUSICA_CNR_LEVEL && env_int("MUSICA_TUNE_SDEV", 1) != 0},
         };
         for (auto& j : jobs) {
             if (!j.use) continue;
