@@ -120,6 +120,7 @@ class ShardPipeline:
         self.batch = batch
         self.steps = 0
         self.calibration = None   # {first context of the window: ms per step} once prime() has chosen
+        self._images = None
 
     def upload(self, images):
         """The shard resident in every context's input buffer (one array for all, or one per context in flight)."""
