@@ -88,9 +88,10 @@ class ShardPipeline:
     the gaps between dependent launches, during which a lone context leaves most of the GPU idle (~a sixth of a step).
     Contexts in flight fill each other's bubbles. Each context here is created with MUSICA_FLAG_LINEAR: ONE in-order
     stream, so consecutive contexts land on different hardware queues (the runtime has 4) and no step waits for an
-    event of another queue. 8 x 2048^2 / L6 on MI355X: one three-stream context 0.484 ms per step, one linear context 0.50,
-    two / three / four / six linear contexts in flight 0.41 / 0.375 / 0.405 / 0.375 ms (DESIGN.md, "Steps in flight";
-    one 2048^2 image per step: 0.213 -> 0.093 ms; more than 4 hardware queues are worse).
+    event of another queue. 8 x 2048^2 / L6 on MI355X, the build that introduced this: one three-stream context 0.484 ms per
+    step, one linear context 0.50, two / three / four / six linear contexts in flight 0.41 / 0.375 / 0.405 / 0.375 ms (end
+    of round 2: 0.44 / 0.46 / 0.38 / 0.35 - 0.36; DESIGN.md, "Steps in flight"; one 2048^2 image per step: 0.213 -> 0.093 ms;
+    more than 4 hardware queues are worse).
     Every context owns its buffers, stream and captured graph; a step's results are bit-identical to a lone
     context's (tests/test_gpu_parity.py). The reference has one VulkanProcessing per process and one frame in flight
     (src/vk_processing.cpp:2104-2601); this is the batch driver's throughput form of it.
