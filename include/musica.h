@@ -239,9 +239,18 @@ int musica_get_clahe_curves(musica_ctx* ctx, uint32_t image_index, musica_point*
  * norm.bmp, red_bandpass_i.bmp, red_lowpass_i.bmp, sdev.bmp, cnr.bmp,
  * exp_bandpass_i.bmp, exp_lowpass_i.bmp, relevant.bmp, graded.bmp (same
  * quantisation as VulkanState::downloadAndSaveImage, src/vk_state.cpp:809-855)
- * into `dir`, plus noise_hist.csv / grad_hist.csv / curves as CSV instead of
- * the rendered RGBA plots. */
+ * into `dir`, the two RGBA plots noise_hist.bmp / grad_hist.bmp, and (an addition)
+ * noise_hist.csv / grad_hist.csv / grad_curve.csv with the numbers behind them. */
 int musica_debug_process(musica_ctx* ctx, uint32_t image_index, const char* dir);
+/* The two RGBA plots the reference renders on every execute (#define RENDER_HISTS, include/vk_processing.h:22) and
+ * debugProcess writes as noise_hist.bmp / grad_hist.bmp (src/vk_processing.cpp:2758-2806): noise_hist_render.comp on the
+ * histogram of cnrLevel (:1260-1266) and gradation_curve_debug_render.comp on the gradation histogram + tone curve
+ * (:1668-1675), each one workgroup of 512 invocations on a histRenderWidth x histRenderHeight rgba8 image
+ * (include/vk_processing.h:31-32). `rgba`: MUSICA_HIST_RENDER_WIDTH * MUSICA_HIST_RENDER_HEIGHT * 4 bytes, top row first. */
+#define MUSICA_HIST_RENDER_WIDTH 512
+#define MUSICA_HIST_RENDER_HEIGHT 128
+int musica_render_noise_hist(musica_ctx* ctx, uint32_t image_index, uint8_t* rgba);
+int musica_render_grad_hist(musica_ctx* ctx, uint32_t image_index, uint8_t* rgba);
 
 /* ---- test / profiling hooks ------------------------------------------ */
 
@@ -334,6 +343,8 @@ int musica_memcpy_d2h(musica_ctx* ctx, void* dst, const void* d_src, size_t byte
 int musica_read_raw(const char* path, uint32_t image_size, uint16_t* dst);
 /* 24-bpp BMP writer byte-identical to stbi_write_bmp(path, w, h, 1, data). */
 int musica_write_bmp_gray(const char* path, uint32_t w, uint32_t h, const uint8_t* data);
+/* 32-bpp BMP writer byte-identical to stbi_write_bmp(path, w, h, 4, data) (V4 header, stb_image_write.h:501-509). */
+int musica_write_bmp_rgba(const char* path, uint32_t w, uint32_t h, const uint8_t* data);
 
 /* ---- misc ------------------------------------------------------------ */
 const char* musica_last_error(void);

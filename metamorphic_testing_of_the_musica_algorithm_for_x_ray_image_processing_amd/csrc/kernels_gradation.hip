@@ -445,6 +445,72 @@ __global__ __launch_bounds__(256) void k_grad_apply(const float* __restrict__ in
     else grad_apply_loop<0, U>(tab, gl, src, dst, i, stride, total, v);
 }
 
+// ---- the two RGBA plots of #define RENDER_HISTS (include/vk_processing.h:22) -------------------------------
+// noise_hist_render.comp and gradation_curve_debug_render.comp: one workgroup of 512 invocations each on a 512 x 128 rgba8
+// image (src/vk_processing.cpp:2347, :2508; include/vk_processing.h:31-32), invocation x draws column x. The reference renders
+// them on every execute and debugProcess writes them out (:2758-2806); here they are rendered when asked for
+// (musica_render_*_hist, musica_debug_process). A texel is one packed word 0xAABBGGRR; stores outside the image are dropped (Q1).
+constexpr uint32_t kPlotW = MUSICA_HIST_RENDER_WIDTH, kPlotH = MUSICA_HIST_RENDER_HEIGHT;
+constexpr uint32_t kBlack = 0xFF000000u, kWhite = 0xFFFFFFFFu, kRed = 0xFF0000FFu, kGreen = 0xFF00FF00u, kBlue = 0xFFFF0000u, kMagenta = 0xFFFF00FFu;
+__device__ __forceinline__ void plot_store(uint32_t* __restrict__ img, uint32_t x, uint32_t y, uint32_t rgba) {
+    if (x < kPlotW && y < kPlotH) img[y * kPlotW + x] = rgba;
+}
+// uint(float(value) * (float(imageSize.y) / float(maxValue + 1))), clipped as the shaders clip it
+__device__ __forceinline__ uint32_t plot_bar_height(uint32_t value, uint32_t maxValue) {
+    uint32_t h = f2u((float)value * ((float)kPlotH / (float)(maxValue + 1u)));
+    if (h > kPlotH) h = kPlotH - 1u;
+    return h;
+}
+
+// noise_hist_render.comp:17-76 on the cnr level's histogram and argmax (src/vk_processing.cpp:1260-1266); the conversion
+// factor is 1.0: bins 0 .. 511 of the 2048.
+__global__ __launch_bounds__(512) void k_render_noise_hist(const uint32_t* __restrict__ hist, const musica_hist_max_point* __restrict__ maxpt,
+                                                           uint32_t* __restrict__ out) {
+    const uint32_t pos = threadIdx.x;
+    const float factor = 1.0f;
+    const uint32_t bin = f2u((float)pos * factor);
+    const uint32_t value = bin < (uint32_t)MUSICA_NOISE_BINS ? hist[bin] : 0u;
+    const uint32_t bar = plot_bar_height(value, maxpt->maxValue);
+    const uint32_t startY = kPlotH - bar - 1u;
+    for (uint32_t y = 0; y < kPlotH; y++) plot_store(out, pos, y, kBlack);                 // :62-64
+    plot_store(out, pos, kPlotH - 1u, kRed);                                               // :66
+    const bool at_max = bin <= maxpt->maxBin && (float)bin + factor > (float)maxpt->maxBin;
+    for (uint32_t y = startY; y < startY + bar; y++) plot_store(out, pos, y, at_max ? kGreen : kWhite);   // :68-76
+}
+
+// gradation_curve_debug_render.comp:48-123 on the gradation histogram, its argmax and the tone curve
+// (src/vk_processing.cpp:1668-1675). getY (:31-46) is the literal scan with the slope computed in place; x[count], y[count]
+// are the zeros behind the curve.
+__global__ __launch_bounds__(512) void k_render_grad_hist(const uint32_t* __restrict__ hist, const musica_hist_max_point* __restrict__ maxpt,
+                                                          const DevCurve* __restrict__ curve, uint32_t* __restrict__ out) {
+    const uint32_t pos = threadIdx.x;
+    const float factor = (float)MUSICA_GRAD_BINS / 512.0f;
+    const uint32_t bin = f2u((float)pos * factor);
+    const uint32_t value = bin < (uint32_t)MUSICA_GRAD_BINS ? hist[bin] : 0u;
+    const uint32_t bar = plot_bar_height(value, maxpt->maxValue);
+    const uint32_t startY = kPlotH - bar - 1u;
+    plot_store(out, pos, kPlotH - 1u, kRed);                                               // :77
+    const bool at_max = bin <= maxpt->maxBin && (float)bin + factor > (float)maxpt->maxBin;
+    for (uint32_t y = 0; y < kPlotH; y++)                                                  // :79-91
+        plot_store(out, pos, y, (y >= startY && y < startY + bar) ? (at_max ? kMagenta : kWhite) : kBlack);
+    const float step = 1.0f / 512.0f;
+    const float cp = (float)pos * step;                                                    // :94
+    float gy = 0.0f;
+    const uint32_t count = curve->count;
+    for (uint32_t i = 0; i < count; i++) {
+        const float xi = curve->x[i], xn = (i + 1u < (uint32_t)kCurveCap) ? curve->x[i + 1u] : 0.0f, yn = (i + 1u < (uint32_t)kCurveCap) ? curve->y[i + 1u] : 0.0f;
+        if (xi == cp) { gy = curve->y[i]; break; }
+        if (xi <= cp && xn >= cp) { gy = (yn - curve->y[i]) / (xn - xi) * (cp - xi) + curve->y[i]; break; }
+    }
+    const uint32_t posX = f2u(cp * 512.0f * ((float)kPlotW / 512.0f));                     // :99
+    const uint32_t posY = (kPlotH - 1u) - f2u(gy * (float)(kPlotH - 1u));                  // :100
+    const float next = (float)(pos + 1u) * step;
+    if (cp <= curve->t0 && curve->t0 < next) for (uint32_t i = 0; i < kPlotW; i++) plot_store(out, posX, i, kRed);     // :103-107
+    if (cp <= curve->ta && curve->ta < next) for (uint32_t i = 0; i < kPlotW; i++) plot_store(out, posX, i, kGreen);   // :110-114
+    if (cp <= curve->t1 && curve->t1 < next) for (uint32_t i = 0; i < kPlotW; i++) plot_store(out, posX, i, kRed);     // :117-121
+    plot_store(out, posX, posY, kBlue);                                                    // :123
+}
+
 // ======================================================================================
 // host-side launchers
 // ======================================================================================
@@ -495,6 +561,13 @@ void launch_grad_apply(hipStream_t st, const float* in, float* out, const LevelD
     const size_t cap = std::max<size_t>(16384 / (size_t)std::max(batch, 1), 256);
     const int blocks = (int)std::max<size_t>(std::min(want, cap), 1);
     hipLaunchKernelGGL(k_grad_apply, dim3(blocks, 1, batch), dim3(256), 0, st, in, out, l0.S, l0.pitch, l0.plane, curves);
+}
+
+void launch_render_noise_hist(hipStream_t st, const uint32_t* hist, const musica_hist_max_point* maxpt, uint32_t* out) {
+    hipLaunchKernelGGL(k_render_noise_hist, dim3(1), dim3(512), 0, st, hist, maxpt, out);
+}
+void launch_render_grad_hist(hipStream_t st, const uint32_t* hist, const musica_hist_max_point* maxpt, const DevCurve* curve, uint32_t* out) {
+    hipLaunchKernelGGL(k_render_grad_hist, dim3(1), dim3(512), 0, st, hist, maxpt, curve, out);
 }
 
 }  // namespace musica

@@ -84,6 +84,9 @@ void launch_curves_cnr(hipStream_t st, const uint32_t* hist, size_t hist_stride,
                        const LevelDesc& l3, const uint32_t* minmax, int min_chain_exact, int* thr090, int lev0 = 0);
 void launch_cnr(hipStream_t st, const float* sdev, float* cnr, const LevelDesc& l3, const musica_hist_max_point* maxpts, int levels, int batch);
 void launch_selftest_exact_math(hipStream_t st, unsigned long long* d_bad4);
+// the RGBA plots of RENDER_HISTS (kernels_gradation.hip): out = MUSICA_HIST_RENDER_WIDTH x MUSICA_HIST_RENDER_HEIGHT packed texels
+void launch_render_noise_hist(hipStream_t st, const uint32_t* hist, const musica_hist_max_point* maxpt, uint32_t* out);
+void launch_render_grad_hist(hipStream_t st, const uint32_t* hist, const musica_hist_max_point* maxpt, const DevCurve* curve, uint32_t* out);
 constexpr int kStatsMaxBlocks = 64;
 // XCD-aware workgroup -> tile mapping of the marching kernels (kernels_common.h xcd_tile); MUSICA_XCD_SWIZZLE=0 turns it off
 int xcd_swizzle_on();

@@ -99,6 +99,7 @@ struct musica_ctx {
     uint32_t* d_grad_hist_b;   // the literal recount of images whose reconstruction holds an exact zero (fused gradation histogram)
     uint32_t* d_gzero;         // [B]: that condition
     int* d_thr090;             // [B]: raw-pixel form of `normalized <= 0.9`
+    uint32_t* d_plot;          // one MUSICA_HIST_RENDER_WIDTH x MUSICA_HIST_RENDER_HEIGHT rgba8 image (the RENDER_HISTS plots, on demand)
     double* d_stats_partial;   // [B][kStatsMaxBlocks]: partial sums of the cnr image (k_stats_partial -> k_stats)
     uint16_t* d_le090;         // [B][S1][S0 / 8] or null: its bit image, written by the level-0 reduce + band launch for the level-0 expand launch
     bool fuse_gh;              // the level-0 expand launch accumulates the gradation histogram
@@ -461,6 +462,7 @@ static musica_ctx* create_impl(const musica_params* params) {
     ok = ok && dalloc(c, &c->d_gzero, B);
     ok = ok && dalloc(c, &c->d_thr090, B);
     ok = ok && dalloc(c, &c->d_stats_partial, B * kStatsMaxBlocks);
+    ok = ok && dalloc(c, &c->d_plot, (size_t)MUSICA_HIST_RENDER_WIDTH * MUSICA_HIST_RENDER_HEIGHT);
     c->d_le090 = nullptr;
     if (c->fuse_gh && c->fuse_rb >= 1 && env_int("MUSICA_LE090", 1) != 0) ok = ok && dalloc(c, &c->d_le090, B * (size_t)c->lv[1].S * (c->lv[0].S / 8));
     ok = ok && dalloc(c, &c->d_grad_max, B);
@@ -1260,6 +1262,27 @@ int musica_get_grad_curve(musica_ctx* c, uint32_t idx, musica_grad_curve* dst) {
     dst->t0 = dc.t0; dst->ta = dc.ta; dst->t1 = dc.t1;
     return 1;
 }
+// The RENDER_HISTS plots (kernels_gradation.hip k_render_*): rendered into d_plot on the ctx stream, copied out.
+static int plot_out(musica_ctx* c, uint8_t* rgba) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(rgba, c->d_plot, (size_t)MUSICA_HIST_RENDER_WIDTH * MUSICA_HIST_RENDER_HEIGHT * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail("plot read-back failed: %s", hipGetErrorString(e));
+    return 1;
+}
+int musica_render_noise_hist(musica_ctx* c, uint32_t idx, uint8_t* rgba) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    if (!rgba) return fail("musica_render_noise_hist: rgba is NULL");
+    launch_render_noise_hist(c->stream, c->d_noise_hist + ((size_t)idx * 4 + MUSICA_CNR_LEVEL) * MUSICA_NOISE_BINS,
+                             c->d_noise_max + (size_t)idx * c->L + MUSICA_CNR_LEVEL, c->d_plot);   // src/vk_processing.cpp:1260-1266
+    return plot_out(c, rgba);
+}
+int musica_render_grad_hist(musica_ctx* c, uint32_t idx, uint8_t* rgba) {
+    CHECK_CTX(c); CHECK_IMG(c, idx);
+    if (!rgba) return fail("musica_render_grad_hist: rgba is NULL");
+    launch_render_grad_hist(c->stream, c->d_grad_hist + (size_t)idx * MUSICA_GRAD_BINS, c->d_grad_max + idx, c->d_gcurve + idx, c->d_plot);   // :1668-1675
+    return plot_out(c, rgba);
+}
 int musica_get_contrast_params(musica_ctx* c, uint32_t level, musica_contrast_params* dst) {
     if (!c || (int)level >= c->L) return fail("musica_get_contrast_params: bad ctx/level");
     *dst = c->h_cparams[level];
@@ -1354,7 +1377,14 @@ int musica_debug_process(musica_ctx* c, uint32_t idx, const char* dir) {
     }
     if (!dump_image(c, idx, MUSICA_IMG_RELEVANT, 0, d + "relevant.bmp", 1.0f, 0.0f)) return 0;              // :2729-2736
     if (!dump_image(c, idx, MUSICA_IMG_GRADED, 0, d + "graded.bmp", 1.0f, 0.0f)) return 0;                  // :2749-2756
-    // histograms and curves as CSV instead of the rendered RGBA plots (noise_hist.bmp / grad_hist.bmp, :2758-2806)
+    {   // the two RGBA plots, :2758-2806
+        std::vector<uint8_t> plot((size_t)MUSICA_HIST_RENDER_WIDTH * MUSICA_HIST_RENDER_HEIGHT * 4);
+        if (!musica_render_noise_hist(c, idx, plot.data())) return 0;
+        if (!musica_write_bmp_rgba((d + "noise_hist.bmp").c_str(), MUSICA_HIST_RENDER_WIDTH, MUSICA_HIST_RENDER_HEIGHT, plot.data())) return fail("failed to write noise_hist.bmp");
+        if (!musica_render_grad_hist(c, idx, plot.data())) return 0;
+        if (!musica_write_bmp_rgba((d + "grad_hist.bmp").c_str(), MUSICA_HIST_RENDER_WIDTH, MUSICA_HIST_RENDER_HEIGHT, plot.data())) return fail("failed to write grad_hist.bmp");
+    }
+    // and the numbers behind them as CSV (an addition)
     {
         std::vector<uint32_t> h(MUSICA_NOISE_BINS);
         FILE* f = fopen((d + "noise_hist.csv").c_str(), "w");

@@ -61,3 +61,36 @@ extern "C" int musica_write_bmp_gray(const char* path, uint32_t w, uint32_t h, c
     ok = (fclose(f) == 0) && ok;
     return ok ? 1 : 0;
 }
+
+// stbi_write_bmp(path, w, h, comp = 4, data), stb_image_write.h:501-509: BITMAPV4HEADER with BI_BITFIELDS and the masks
+// R 0x00ff0000, G 0x0000ff00, B 0x000000ff, A 0xff000000; rows bottom-up, a pixel as B, G, R, A; no padding.
+extern "C" int musica_write_bmp_rgba(const char* path, uint32_t w, uint32_t h, const uint8_t* data) {
+    if (!path || !data) return 0;
+    FILE* f = fopen(path, "wb");
+    if (!f) return 0;
+    uint8_t hdr[14 + 108] = {0};
+    hdr[0] = 'B'; hdr[1] = 'M';
+    le32(hdr + 2, 14 + 108 + w * h * 4);     // file size
+    le32(hdr + 10, 14 + 108);                // pixel data offset
+    le32(hdr + 14, 108);                     // BITMAPV4HEADER
+    le32(hdr + 18, w);
+    le32(hdr + 22, h);
+    le16(hdr + 26, 1);                       // planes
+    le16(hdr + 28, 32);                      // bits per pixel
+    le32(hdr + 30, 3);                       // BI_BITFIELDS; the five words after it stay 0
+    le32(hdr + 54, 0x00ff0000u);
+    le32(hdr + 58, 0x0000ff00u);
+    le32(hdr + 62, 0x000000ffu);
+    le32(hdr + 66, 0xff000000u);             // colour space, endpoints and gammas stay 0
+    bool ok = fwrite(hdr, 1, sizeof(hdr), f) == sizeof(hdr);
+    std::vector<uint8_t> row((size_t)w * 4);
+    for (int64_t j = (int64_t)h - 1; j >= 0 && ok; j--) {
+        const uint8_t* src = data + (size_t)j * w * 4;
+        for (uint32_t i = 0; i < w; i++) {
+            row[4 * i] = src[4 * i + 2]; row[4 * i + 1] = src[4 * i + 1]; row[4 * i + 2] = src[4 * i]; row[4 * i + 3] = src[4 * i + 3];
+        }
+        ok = fwrite(row.data(), 1, row.size(), f) == row.size();
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? 1 : 0;
+}

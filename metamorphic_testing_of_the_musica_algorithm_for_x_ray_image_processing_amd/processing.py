@@ -24,6 +24,8 @@ NOISE_BINS = 2048
 GRAD_BINS = 1024
 OUT_MARGIN = 10
 
+HIST_RENDER_WIDTH, HIST_RENDER_HEIGHT = 512, 128   # histRenderWidth / histRenderHeight, include/vk_processing.h:31-32
+
 FLAG_CLAHE = 0x1
 FLAG_NO_GRAPH = 0x2
 FLAG_GENERIC_KERNELS = 0x4
@@ -130,6 +132,8 @@ ABI = {
     "musica_get_clahe_hist": (C.c_int, [_VP, C.c_uint32, _U32P]),
     "musica_get_clahe_curves": (C.c_int, [_VP, C.c_uint32, C.POINTER(Point)]),
     "musica_debug_process": (C.c_int, [_VP, C.c_uint32, C.c_char_p]),
+    "musica_render_noise_hist": (C.c_int, [_VP, C.c_uint32, _U8P]),
+    "musica_render_grad_hist": (C.c_int, [_VP, C.c_uint32, _U8P]),
     "musica_debug_set_image": (C.c_int, [_VP, C.c_uint32, C.c_int, C.c_uint32, _F32P]),
     "musica_debug_run_stage": (C.c_int, [_VP, C.c_int]),
     "musica_profile_enable": (C.c_int, [_VP, C.c_int]),
@@ -146,6 +150,7 @@ ABI = {
     "musica_memcpy_d2h": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
     "musica_read_raw": (C.c_int, [C.c_char_p, C.c_uint32, _U16P]),
     "musica_write_bmp_gray": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _U8P]),
+    "musica_write_bmp_rgba": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _U8P]),
     "musica_last_error": (C.c_char_p, []),
     "musica_abi_version": (C.c_uint32, []),
     "musica_device_count": (C.c_int, []),
@@ -221,6 +226,18 @@ class MusicaProcessing:
     def debugProcess(self, directory=".", image_index=0):
         """bool debugProcess() — src/vk_processing.cpp:2661-2809 (the reference writes into the cwd)."""
         return self._lib.musica_debug_process(self._h, image_index, os.fsencode(directory)) == 1
+
+    def render_noise_hist(self, image_index=0):
+        """noise_hist_render.comp on the cnr level's histogram (RENDER_HISTS, src/vk_processing.cpp:1260-1266, :2347): uint8 [128, 512, 4]."""
+        out = np.empty((HIST_RENDER_HEIGHT, HIST_RENDER_WIDTH, 4), dtype=np.uint8)
+        self._ok(self._lib.musica_render_noise_hist(self._h, image_index, out.ctypes.data_as(_U8P)), "musica_render_noise_hist")
+        return out
+
+    def render_grad_hist(self, image_index=0):
+        """gradation_curve_debug_render.comp on the gradation histogram + tone curve (src/vk_processing.cpp:1668-1675, :2508)."""
+        out = np.empty((HIST_RENDER_HEIGHT, HIST_RENDER_WIDTH, 4), dtype=np.uint8)
+        self._ok(self._lib.musica_render_grad_hist(self._h, image_index, out.ctypes.data_as(_U8P)), "musica_render_grad_hist")
+        return out
 
     def cleanup(self):
         """bool cleanup() — src/vk_processing.cpp:2647-2651."""
@@ -513,3 +530,10 @@ def write_bmp_gray(path, data):
     d = np.ascontiguousarray(data, dtype=np.uint8)
     h, w = d.shape
     return load_library().musica_write_bmp_gray(os.fsencode(path), w, h, d.ctypes.data_as(_U8P)) == 1
+
+
+def write_bmp_rgba(path, data):
+    d = np.ascontiguousarray(data, dtype=np.uint8)
+    h, w, c = d.shape
+    assert c == 4
+    return load_library().musica_write_bmp_rgba(os.fsencode(path), w, h, d.ctypes.data_as(_U8P)) == 1

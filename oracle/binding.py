@@ -139,6 +139,12 @@ def lib():
     L.musica_oracle_debug_process.argtypes = [vp, C.c_char_p]
     L.musica_oracle_write_bmp_gray.restype = C.c_int
     L.musica_oracle_write_bmp_gray.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, u8p]
+    L.musica_oracle_write_bmp_rgba.restype = C.c_int
+    L.musica_oracle_write_bmp_rgba.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, u8p]
+    L.musica_oracle_render_noise_hist.restype = None
+    L.musica_oracle_render_noise_hist.argtypes = [vp, u8p]
+    L.musica_oracle_render_grad_hist.restype = None
+    L.musica_oracle_render_grad_hist.argtypes = [vp, u8p]
     L.musica_oracle_read_raw.restype = C.c_int
     L.musica_oracle_read_raw.argtypes = [C.c_char_p, C.c_uint32, u16p]
     # single-shader entry points
@@ -278,6 +284,16 @@ class Oracle:
         n = self.N - 20
         out = np.empty((n, n), dtype=np.uint8)
         assert self.L.musica_oracle_out_pixels(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8))) == 1
+        return out
+
+    def render_noise_hist(self):
+        out = np.empty((128, 512, 4), dtype=np.uint8)
+        self.L.musica_oracle_render_noise_hist(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return out
+
+    def render_grad_hist(self):
+        out = np.empty((128, 512, 4), dtype=np.uint8)
+        self.L.musica_oracle_render_grad_hist(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8)))
         return out
 
     def debug_process(self, directory):
@@ -464,6 +480,13 @@ def write_bmp_gray(path, data):
     assert lib().musica_oracle_write_bmp_gray(os.fsencode(path), w, h, d.ctypes.data_as(C.POINTER(C.c_uint8))) == 1
 
 
+def write_bmp_rgba(path, data):
+    d = np.ascontiguousarray(data, dtype=np.uint8)
+    h, w, c = d.shape
+    assert c == 4
+    assert lib().musica_oracle_write_bmp_rgba(os.fsencode(path), w, h, d.ctypes.data_as(C.POINTER(C.c_uint8))) == 1
+
+
 def read_raw(path, image_size):
     out = np.empty((image_size, image_size), dtype=np.uint16)
     ok = lib().musica_oracle_read_raw(os.fsencode(path), image_size, out.ctypes.data_as(C.POINTER(C.c_uint16)))
@@ -482,3 +505,14 @@ def ref_write_bmp_gray(path, data):
     d = np.ascontiguousarray(data, dtype=np.uint8)
     h, w = d.shape
     assert L.ref_write_bmp_gray(os.fsencode(path), w, h, d.ctypes.data_as(C.POINTER(C.c_uint8))) != 0
+
+
+def ref_write_bmp_rgba(path, data):
+    """The REFERENCE's stbi_write_bmp with four components, as debugProcess calls it for its two plots."""
+    L = C.CDLL(REF_BMP_PATH)
+    L.ref_write_bmp_rgba.restype = C.c_int
+    L.ref_write_bmp_rgba.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+    d = np.ascontiguousarray(data, dtype=np.uint8)
+    h, w, c = d.shape
+    assert c == 4
+    assert L.ref_write_bmp_rgba(os.fsencode(path), w, h, d.ctypes.data_as(C.POINTER(C.c_uint8))) != 0

@@ -982,6 +982,114 @@ int musica_oracle_write_bmp_gray(const char* path, uint32_t w, uint32_t h, const
     return 1;
 }
 
+/* stbi_write_bmp(path, w, h, comp = 4, data): dependencies/stb/stb_image_write.h:501-509 — a V4 header (108 bytes, BI_BITFIELDS,
+ * masks 0xff0000 / 0xff00 / 0xff / 0xff000000), pixels :451-476 bottom-up as B, G, R, A, no row padding. What debugProcess
+ * writes for its two RGBA plots (src/vk_processing.cpp:2758-2806). */
+int musica_oracle_write_bmp_rgba(const char* path, uint32_t w, uint32_t h, const uint8_t* data) {
+    FILE* f = fopen(path, "wb");
+    if (!f) return 0;
+    fputc('B', f); fputc('M', f);
+    put_u32(f, 14 + 108 + w * h * 4);
+    put_u16(f, 0); put_u16(f, 0);
+    put_u32(f, 14 + 108);
+    put_u32(f, 108); put_u32(f, w); put_u32(f, h);
+    put_u16(f, 1); put_u16(f, 32);
+    put_u32(f, 3);
+    for (int i = 0; i < 5; i++) put_u32(f, 0);
+    put_u32(f, 0xff0000u); put_u32(f, 0xff00u); put_u32(f, 0xffu); put_u32(f, 0xff000000u);
+    for (int i = 0; i < 13; i++) put_u32(f, 0);          /* cstype, 9 endpoint words, 3 gamma words */
+    for (int32_t j = (int32_t)h - 1; j >= 0; j--)
+        for (uint32_t i = 0; i < w; i++) {
+            const uint8_t* q = data + ((size_t)j * w + i) * 4;
+            fputc(q[2], f); fputc(q[1], f); fputc(q[0], f); fputc(q[3], f);
+        }
+    fclose(f);
+    return 1;
+}
+
+/* ---- the two RGBA plots the reference renders on every execute (#define RENDER_HISTS, include/vk_processing.h:22) ---------
+ * Both shaders run as ONE workgroup of 512 invocations (execute(1, 1), src/vk_processing.cpp:2347, :2508) on a
+ * histRenderWidth x histRenderHeight = 512 x 128 rgba8 image (include/vk_processing.h:31-32); invocation x draws column x.
+ * imageStore outside the image is dropped (Q1); a stored vec4 component 0 / 1 is the byte 0 / 255. */
+static void plot_px(uint8_t* img, uint32_t x, uint32_t y, uint8_t r, uint8_t g, uint8_t b) {
+    if (x >= MUSICA_HIST_RENDER_W || y >= MUSICA_HIST_RENDER_H) return;
+    uint8_t* q = img + ((size_t)y * MUSICA_HIST_RENDER_W + x) * 4;
+    q[0] = r; q[1] = g; q[2] = b; q[3] = 255;
+}
+
+/* noise_hist_render.comp:17-76 bound to the histogram and the argmax of cnrLevel (src/vk_processing.cpp:1260-1266):
+ * positionConversionFactor is 1.0, so only bins 0..511 of the 2048 are drawn, one per column. */
+void musica_oracle_render_noise_hist(const musica_oracle* o, uint8_t* rgba) {
+    const uint32_t H = MUSICA_HIST_RENDER_H;
+    const uint32_t maxValue = o->noise_max[MUSICA_CNR_LEVEL].maxValue, maxBin = o->noise_max[MUSICA_CNR_LEVEL].maxBin;
+    memset(rgba, 0, (size_t)MUSICA_HIST_RENDER_W * H * 4);
+    for (uint32_t pos = 0; pos < MUSICA_HIST_RENDER_W; pos++) {
+        const float factor = 1.0f;                                                    /* :19 */
+        const uint32_t bin = f2u((float)pos * factor);                                /* :23 */
+        const uint32_t value = bin < MUSICA_NOISE_BINS ? o->noise_hist[MUSICA_CNR_LEVEL][bin] : 0u;   /* :41 */
+        uint32_t barHeight = f2u((float)value * ((float)H / (float)(maxValue + 1u))); /* :49 */
+        if (barHeight > H) barHeight = H - 1u;                                        /* :50 */
+        const uint32_t startY = H - barHeight - 1u;                                   /* :58 (uint arithmetic) */
+        for (uint32_t y = 0; y < H; y++) plot_px(rgba, pos, y, 0, 0, 0);              /* :62-64 */
+        plot_px(rgba, pos, H - 1u, 255, 0, 0);                                        /* :66 */
+        for (uint32_t y = startY; y < startY + barHeight; y++) {                      /* :68-76, barWidth = 1 */
+            if (bin <= maxBin && (float)bin + factor > (float)maxBin) plot_px(rgba, pos, y, 0, 255, 0);
+            else plot_px(rgba, pos, y, 255, 255, 255);
+        }
+    }
+}
+
+/* getY() of gradation_curve_debug_render.comp:31-46: first i < pointsCount with points[i].x == x, or points[i].x <= x <=
+ * points[i + 1].x (points[pointsCount] is the never-written entry behind the curve: 0, 0), m * (x - x_i) + y_i. */
+static float plot_get_y(const musica_point* pts, uint32_t count, float x) {
+    for (uint32_t i = 0; i < count; i++) {
+        if (pts[i].x == x) return pts[i].y;
+        if (pts[i].x <= x && pts[i + 1].x >= x) {
+            const float m = (pts[i + 1].y - pts[i].y) / (pts[i + 1].x - pts[i].x);
+            return m * (x - pts[i].x) + pts[i].y;
+        }
+    }
+    return 0.0f;
+}
+
+/* gradation_curve_debug_render.comp:48-123 bound to the gradation histogram, its argmax and the tone curve
+ * (src/vk_processing.cpp:1668-1675): every SECOND histogram bin (factor 1024 / 512 = 2), the t0 / ta / t1 columns, the curve. */
+void musica_oracle_render_grad_hist(const musica_oracle* o, uint8_t* rgba) {
+    const uint32_t H = MUSICA_HIST_RENDER_H, W = MUSICA_HIST_RENDER_W;
+    const uint32_t maxValue = o->grad_max.maxValue, maxBin = o->grad_max.maxBin;
+    const musica_grad_curve* gc = &o->gcurve.c;
+    memset(rgba, 0, (size_t)W * H * 4);
+    for (uint32_t pos = 0; pos < W; pos++) {
+        const float factor = (float)MUSICA_GRAD_BINS / 512.0f;                        /* :52 */
+        const uint32_t bin = f2u((float)pos * factor);                                /* :54 */
+        const uint32_t value = bin < MUSICA_GRAD_BINS ? o->grad_hist[bin] : 0u;       /* :56 */
+        uint32_t barHeight = f2u((float)value * ((float)H / (float)(maxValue + 1u))); /* :64 */
+        if (barHeight > H) barHeight = H - 1u;                                        /* :65 */
+        const uint32_t startY = H - barHeight - 1u;                                   /* :73 */
+        plot_px(rgba, pos, H - 1u, 255, 0, 0);                                        /* :77 (overwritten by the loop below) */
+        for (uint32_t y = 0; y < H; y++) {                                            /* :79-91 */
+            if (y >= startY && y < startY + barHeight) {
+                if (bin <= maxBin && (float)bin + factor > (float)maxBin) plot_px(rgba, pos, y, 255, 0, 255);
+                else plot_px(rgba, pos, y, 255, 255, 255);
+            } else {
+                plot_px(rgba, pos, y, 0, 0, 0);
+            }
+        }
+        const float step = 1.0f / 512.0f;
+        const float cp = (float)pos * step;                                           /* :94 */
+        const uint32_t posX = f2u(cp * 512.0f * ((float)W / 512.0f));                 /* :99 */
+        const uint32_t posY = (H - 1u) - f2u(plot_get_y(gc->points, gc->pointsCount, cp) * (float)(H - 1u));   /* :100 */
+        const float next = (float)(pos + 1u) * step;
+        if (cp <= gc->t0 && gc->t0 < next)                                            /* :103-107: i runs to imageSize.x, rows >= H are dropped */
+            for (uint32_t i = 0; i < W; i++) plot_px(rgba, posX, i, 255, 0, 0);
+        if (cp <= gc->ta && gc->ta < next)                                            /* :110-114 */
+            for (uint32_t i = 0; i < W; i++) plot_px(rgba, posX, i, 0, 255, 0);
+        if (cp <= gc->t1 && gc->t1 < next)                                            /* :117-121 */
+            for (uint32_t i = 0; i < W; i++) plot_px(rgba, posX, i, 255, 0, 0);
+        plot_px(rgba, posX, posY, 0, 0, 255);                                         /* :123 */
+    }
+}
+
 int musica_oracle_save_out_image(const musica_oracle* o, const char* path) {
     uint32_t nw = o->N - 2 * MUSICA_OUT_MARGIN;
     uint8_t* buf = (uint8_t*)malloc((size_t)nw * nw);
@@ -1012,7 +1120,7 @@ static int dump_image(const float* img, uint32_t side, const char* dir, const ch
 /* VulkanProcessing::debugProcess, src/vk_processing.cpp:2661-2756: the image dumps, in the reference's order and with its
  * (max, min) pairs. Slot i of the expand-side arrays is level L-1-i (src/vk_processing.cpp:930-934, 1099-1111);
  * expandBandpassImageStates is the output of contrast_curve_apply (before noise reduction). The two RGBA plots
- * (noise_hist.bmp, grad_hist.bmp, :2758-2806) come from render shaders that are out of scope. */
+ * (noise_hist.bmp, grad_hist.bmp, :2758-2806) are the render shaders' images of the last execute. */
 int musica_oracle_debug_process(const musica_oracle* o, const char* dir) {
     char name[64];
     int ok = dump_image(o->normalized, o->N, dir, "norm.bmp", 1.0f, 0.0f);                          /* :2664-2671 */
@@ -1033,6 +1141,17 @@ int musica_oracle_debug_process(const musica_oracle* o, const char* dir) {
     }
     ok = ok && dump_image(o->relevant, o->N, dir, "relevant.bmp", 1.0f, 0.0f);                     /* :2729-2736 */
     ok = ok && dump_image(o->graded, o->N, dir, "graded.bmp", 1.0f, 0.0f);                         /* :2749-2756 */
+    if (ok) {                                                                                       /* :2758-2806 */
+        uint8_t* plot = (uint8_t*)malloc((size_t)MUSICA_HIST_RENDER_W * MUSICA_HIST_RENDER_H * 4);
+        char path[4096];
+        musica_oracle_render_noise_hist(o, plot);
+        snprintf(path, sizeof(path), "%s/noise_hist.bmp", dir && *dir ? dir : ".");
+        ok = musica_oracle_write_bmp_rgba(path, MUSICA_HIST_RENDER_W, MUSICA_HIST_RENDER_H, plot);
+        musica_oracle_render_grad_hist(o, plot);
+        snprintf(path, sizeof(path), "%s/grad_hist.bmp", dir && *dir ? dir : ".");
+        ok = ok && musica_oracle_write_bmp_rgba(path, MUSICA_HIST_RENDER_W, MUSICA_HIST_RENDER_H, plot);
+        free(plot);
+    }
     return ok;
 }
 

@@ -90,6 +90,14 @@ int musica_oracle_save_out_image(const musica_oracle* o, const char* path);
 /* debugProcess (src/vk_processing.cpp:2661-2756): the image dumps norm / red_bandpass_i / red_lowpass_i / sdev / cnr /
  * exp_bandpass_i / exp_lowpass_i / relevant / graded as 8-bit BMPs into `dir` (quantised as src/vk_state.cpp:834). */
 int musica_oracle_debug_process(const musica_oracle* o, const char* dir);
+/* The two RGBA plots of #define RENDER_HISTS (noise_hist_render.comp on the cnr level, gradation_curve_debug_render.comp):
+ * MUSICA_HIST_RENDER_W x MUSICA_HIST_RENDER_H x 4 bytes, row-major, top row first. */
+#define MUSICA_HIST_RENDER_W 512u
+#define MUSICA_HIST_RENDER_H 128u
+void musica_oracle_render_noise_hist(const musica_oracle* o, uint8_t* rgba);
+void musica_oracle_render_grad_hist(const musica_oracle* o, uint8_t* rgba);
+/* stbi_write_bmp(path, w, h, 4, data) restated (stb_image_write.h:501-509). */
+int musica_oracle_write_bmp_rgba(const char* path, uint32_t w, uint32_t h, const uint8_t* data);
 /* stbi_write_bmp(path, w, h, 1, data) restated (stb_image_write.h:492-500). */
 int musica_oracle_write_bmp_gray(const char* path, uint32_t w, uint32_t h, const uint8_t* data);
 /* Raw reader of test/standalone/main.cpp:54-75. */

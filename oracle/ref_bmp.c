@@ -15,3 +15,8 @@
 int ref_write_bmp_gray(const char* path, int w, int h, const unsigned char* data) {
     return stbi_write_bmp(path, w, h, 1, data);
 }
+
+/* debugProcess writes its two plots with four components (src/vk_processing.cpp:2774-2780, :2799-2805). */
+int ref_write_bmp_rgba(const char* path, int w, int h, const unsigned char* data) {
+    return stbi_write_bmp(path, w, h, 4, data);
+}

@@ -570,7 +570,7 @@ def test_save_out_image_and_debug_process(ob, tmp_path):
     e.mkdir()
     assert p.debugProcess(str(d))
     o.debug_process(str(e))
-    images = ["norm.bmp", "sdev.bmp", "cnr.bmp", "relevant.bmp", "graded.bmp"] + \
+    images = ["norm.bmp", "sdev.bmp", "cnr.bmp", "relevant.bmp", "graded.bmp", "noise_hist.bmp", "grad_hist.bmp"] + \
              ["red_bandpass_%d.bmp" % i for i in range(levels)] + ["red_lowpass_%d.bmp" % i for i in range(levels)] + \
              ["exp_bandpass_%d.bmp" % i for i in range(levels)] + ["exp_lowpass_%d.bmp" % i for i in range(levels)]
     assert sorted(f.name for f in e.iterdir()) == sorted(images)
@@ -579,6 +579,10 @@ def test_save_out_image_and_debug_process(ob, tmp_path):
         assert want in names, want
     for name in images:
         assert (d / name).read_bytes() == (e / name).read_bytes(), name
+    # the two RGBA plots (RENDER_HISTS): 512 x 128, four components, V4 header (stbi_write_bmp comp = 4)
+    raw = (d / "noise_hist.bmp").read_bytes()
+    assert len(raw) == 14 + 108 + 512 * 128 * 4 and int.from_bytes(raw[18:22], "little") == 512 and int.from_bytes(raw[22:26], "little") == 128
+    assert np.array_equal(p.render_noise_hist(), o.render_noise_hist()) and np.array_equal(p.render_grad_hist(), o.render_grad_hist())
     # graded.bmp is the un-cropped 8-bit image; the level-3 dumps have side N / 8
     raw = (d / "graded.bmp").read_bytes()
     assert int.from_bytes(raw[18:22], "little") == n
@@ -660,4 +664,25 @@ def test_clahe_context_with_and_without_the_raw_pixel_relevant_image(ob, fuse, m
     a, b = p.clahe_curves(), o.clahe_curves()
     assert ((a == b) | (np.isnan(a) & np.isnan(b))).all()
     _same(p.image(mp.IMG_CLAHE_GRADED), o.image(ob.IMG_CLAHE_GRADED), "clahe graded")
+    p.cleanup()
+
+
+@pytest.mark.parametrize("n,levels,seed,batch", [(1024, 6, 5, 1), (520, 5, 12, 3), (2048, 6, 100, 1)])
+def test_histogram_plots_equal_the_oracles(ob, n, levels, seed, batch):
+    """The RENDER_HISTS plots (noise_hist_render.comp on the cnr level, gradation_curve_debug_render.comp): the HIP kernels'
+    512 x 128 rgba8 images against the oracle's restatement, texel for texel, for every image of a batch; and they are
+    not trivially empty (bars, the argmax colour, the three window columns and the curve are there)."""
+    px = np.stack([phantom(n, seed + k) for k in range(batch)])
+    p = _proc(n, levels, batch=batch)
+    assert p.execute(px if batch > 1 else px[0]), mp.last_error()
+    for k in range(batch):
+        o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[k])
+        a, b = p.render_noise_hist(k), o.render_noise_hist()
+        assert np.array_equal(a, b), "noise plot of image %d" % k
+        c, d = p.render_grad_hist(k), o.render_grad_hist()
+        assert np.array_equal(c, d), "gradation plot of image %d" % k
+        assert (a[..., 3] == 255).all() and (c[..., 3] == 255).all()
+        assert (a[..., :3] == [0, 255, 0]).all(axis=-1).any() or o.noise_hist_max(3)[1] >= 512      # the argmax bar is green
+        assert (c[..., :3] == [0, 0, 255]).all(axis=-1).sum() >= 256                                # the curve, one texel per column
+        assert (c[..., :3] == [0, 255, 0]).all(axis=-1).sum() >= 127                                # the ta column
     p.cleanup()
