@@ -613,6 +613,16 @@ def test_cli_drop_in(ob, tmp_path):
     ref = tmp_path / "oracle.bmp"
     o.save_out_image(str(ref))
     assert out.read_bytes() == ref.read_bytes()
+    # --debug-dir: what a debug build of the reference's harness dumps after execute (main.cpp:81-84 -> debugProcess)
+    dd, de = tmp_path / "cli_dump", tmp_path / "cli_dump_oracle"
+    dd.mkdir()
+    de.mkdir()
+    r = subprocess.run([mp.CLI_PATH, str(raw), str(out), "--size", str(n), "--debug-dir", str(dd)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    o.debug_process(str(de))
+    for f in sorted(de.iterdir()):
+        assert (dd / f.name).read_bytes() == f.read_bytes(), f.name
+    assert (dd / "noise_hist.bmp").exists() and (dd / "grad_hist.bmp").exists()
     # wrong file size -> MAIN ERROR, exit code 1 (main.cpp:57-60)
     r = subprocess.run([mp.CLI_PATH, str(raw), str(out), "--size", "256"], capture_output=True, text=True)
     assert r.returncode == 1 and "MAIN ERROR: the image data don't match the actual image size" in r.stderr
