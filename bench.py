@@ -5,7 +5,7 @@
 
 One "step" = one pass of the whole hot path (minmax -> pyramid reduce -> analysis -> contrast /
 noise-reduction + expand -> gradation) over one batch of synthetic raw images already resident in
-HBM. Steps alternate over --in-flight contexts (default 3, batch.ShardPipeline: step s is enqueued on context s mod 3, each
+HBM. Steps alternate over --in-flight contexts (default 3, the C ABI's musica_pipeline_*: step s is enqueued on context s mod 3, each
 context with its own copy of the input, its own buffers and ONE in-order stream, so the chip-filling kernels of a step
 run in the part-idle phases of the two steps beside it); `one_context` in the JSON line is the same K steps on a single
 three-stream context, each step behind the previous one. After the W warm-up steps the whole job (the same K steps + its
@@ -100,7 +100,7 @@ def parse_args():
     ap.add_argument("--workload", default="C4", type=str.upper, choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--in-flight", type=int, default=3,
-                    help="contexts whose steps alternate (batch.ShardPipeline): step s runs on context s mod D, so the head of a step fills the "
+                    help="contexts whose steps alternate (musica_pipeline_*): step s runs on context s mod D, so the head of a step fills the "
                          "part-idle tail of the one before; 1 = one context, every step behind the previous one")
     ap.add_argument("--batch", type=int, default=0, help="override the workload's images per GPU per step (experiments only)")
     ap.add_argument("--kernel-events", action="store_true",
@@ -194,14 +194,14 @@ def main():
 
     depth = 1 if args.kernel_events else max(1, args.in_flight)   # events inside the timed steps need the one profiled context
     try:
-        pipe = mb.ShardPipeline(n, levels=levels, batch=batch, depth=depth, flags=flags, device=local_rank)
+        pipe = mp.MusicaPipeline(n, levels=levels, batch=batch, depth=depth, flags=flags, device=local_rank)   # the C ABI's musica_pipeline_*
     except RuntimeError as e:
         raise SystemExit(str(e))
     pipe.upload(px)                                                # inputs resident in HBM (one copy per context) before the timed region
     pipe.prime()                                                   # every context has captured its graph; the best set of hardware queues is kept
-    queue_calibration = pipe.calibration
+    queue_calibration = {str(k): round(v, 4) for k, v in pipe.calibration().items()} or None
     if depth == 1:
-        proc = pipe.contexts[0]
+        proc = pipe.context(0)
     else:                                                          # the per-kernel passes and the other measurements: one default (three-stream) context
         proc = mp.MusicaProcessing(device=local_rank)
         if not proc.init(n, levels=levels, batch=batch, flags=flags):
@@ -290,9 +290,7 @@ def main():
     prof_timed = proc.profile()
     # the same K steps on ONE context (every step behind the previous one): reported beside `value`
     if depth > 1:
-        for q in pipe.contexts[1:]:                                # keep one pipeline context for the record, free the others
-            q.cleanup()
-        pipe.contexts = pipe.contexts[:1]
+        pipe.cleanup()                                             # the timed pipeline's contexts are no longer needed
     step_one()
     proc.sync()
     ts0 = time.perf_counter()

@@ -252,6 +252,36 @@ int musica_debug_process(musica_ctx* ctx, uint32_t image_index, const char* dir)
 int musica_render_noise_hist(musica_ctx* ctx, uint32_t image_index, uint8_t* rgba);
 int musica_render_grad_hist(musica_ctx* ctx, uint32_t image_index, uint8_t* rgba);
 
+/* ---- steps in flight (new, not in the reference) ----------------------- */
+
+/* The reference has one VulkanProcessing and one frame in flight (vkWaitForFences at the end of execute,
+ * src/vk_processing.cpp:2535-2536). A pipeline is `depth` contexts of one GPU, each created from `params` with
+ * MUSICA_FLAG_LINEAR, whose steps alternate: step s is enqueued (asynchronously) on context s mod depth, so the chip-filling
+ * kernels of a step run in the part-idle phases of the steps beside it (three contexts: +23 % throughput at 8 x 2048^2,
+ * 2.3 x for one image per step). musica_pipeline_prime() captures every context's graph and chooses WHICH hardware queues
+ * stay: it creates one context per queue of the runtime (MUSICA_PIPELINE_QUEUES), times every cyclic window of `depth` of
+ * them for `calibration_steps` steps (0: three per context) and destroys the contexts outside the fastest window — two of
+ * the four queues of an MI355X do not run side by side. Order of calls: create, upload (or fill every context's input
+ * through musica_pipeline_context), prime, then step / sync at will. A context runs its own steps in order: the results of
+ * the step a context ran last are valid after musica_sync of that context (or musica_pipeline_sync) and before its next step. */
+typedef struct musica_pipeline musica_pipeline;
+#define MUSICA_PIPELINE_QUEUES 4
+musica_pipeline* musica_pipeline_create(const musica_params* params, uint32_t depth);
+void musica_pipeline_destroy(musica_pipeline* p);
+uint32_t musica_pipeline_depth(const musica_pipeline* p);
+/* k-th context: before prime() k < max(depth, MUSICA_PIPELINE_QUEUES) (depth 1: one), afterwards k < depth, in step order. */
+musica_ctx* musica_pipeline_context(musica_pipeline* p, uint32_t k);
+/* The same batch (batch x N x N uint16, host memory) into the input buffer of every context. */
+int musica_pipeline_upload(musica_pipeline* p, const uint16_t* pixels);
+int musica_pipeline_prime(musica_pipeline* p, uint32_t calibration_steps);
+/* ms per step of the windows prime() timed (window k starts at the k-th created context); returns how many (0: none). */
+uint32_t musica_pipeline_calibration(const musica_pipeline* p, float* window_ms /* [MUSICA_PIPELINE_QUEUES] or NULL */);
+/* Enqueue one step on the next context: d_pixels (device memory, 16-byte aligned) or, when NULL, that context's own input. */
+int musica_pipeline_step(musica_pipeline* p, const uint16_t* d_pixels);
+/* The context the most recent step was enqueued on. */
+musica_ctx* musica_pipeline_last(musica_pipeline* p);
+int musica_pipeline_sync(musica_pipeline* p);
+
 /* ---- test / profiling hooks ------------------------------------------ */
 
 /* A sequence of `count` batches (pixels[j]: batch x N x N uint16 in host memory), pipelined: two device input buffers and a

@@ -94,7 +94,9 @@ class ShardPipeline:
     more than 4 hardware queues are worse).
     Every context owns its buffers, stream and captured graph; a step's results are bit-identical to a lone
     context's (tests/test_gpu_parity.py). The reference has one VulkanProcessing per process and one frame in flight
-    (src/vk_processing.cpp:2104-2601); this is the batch driver's throughput form of it.
+    (src/vk_processing.cpp:2104-2601); this is the batch driver's throughput form of it. The C ABI has the same object
+    (musica_pipeline_*, processing.MusicaPipeline — what bench.py times); this class is its logic in Python, on top of
+    MusicaProcessing, so that the choice of queues can be exercised without a GPU (tests/test_distributed.py).
     """
 
     HW_QUEUES = 4   # the HIP runtime's default number of hardware queues per process (GPU_MAX_HW_QUEUES)

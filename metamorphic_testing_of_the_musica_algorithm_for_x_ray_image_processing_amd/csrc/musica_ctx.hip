@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <exception>
 #include <string>
 #include <vector>
@@ -1569,6 +1570,141 @@ int musica_memcpy_d2h(musica_ctx* c, void* dst, const void* d_src, size_t bytes)
     CHECK_CTX(c);
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return 1;
+}
+
+// ---- steps in flight -------------------------------------------------------------------
+// `depth` contexts of one GPU whose steps alternate ("Steps in flight"): every context is created with
+// MUSICA_FLAG_LINEAR (one in-order stream, its script a linear graph), step s is enqueued on context s mod depth and nothing waits.
+// A stream's hardware queue is the runtime's round-robin over every stream the process has created, and two of the four queues
+// of an MI355X do not run side by side, so one context per queue is created and musica_pipeline_prime() times every cyclic
+// window of `depth` of them for a few steps, keeps the fastest and destroys the rest (three contexts: 0.36 ms per 8 x 2048^2
+// step on a good window, 0.41 on a bad one). The reference has one VulkanProcessing and one frame in flight
+// (src/vk_processing.cpp:2535-2536); this is the throughput form of it, for C / C++ callers what batch.ShardPipeline is in Python.
+struct musica_pipeline {
+    std::vector<musica_ctx*> ctx;   // before prime(): one per hardware queue; after: the `depth` that stay, in step order
+    uint32_t depth;
+    uint64_t steps;
+    float window_ms[MUSICA_PIPELINE_QUEUES];
+    uint32_t windows;               // how many windows prime() timed (0: nothing to choose)
+};
+
+static int pipeline_run(const std::vector<musica_ctx*>& use, uint32_t steps) {
+    for (uint32_t s = 0; s < steps; s++) {
+        musica_ctx* c = use[s % use.size()];
+        if (!musica_execute_device(c, c->d_input)) return 0;
+    }
+    for (musica_ctx* c : use)
+        if (!musica_sync(c)) return 0;
+    return 1;
+}
+
+musica_pipeline* musica_pipeline_create(const musica_params* params, uint32_t depth) {
+    if (!params) { fail("musica_pipeline_create: params is NULL"); return nullptr; }
+    if (depth < 1 || depth > 16) { fail("musica_pipeline_create: depth %u out of range [1, 16]", depth); return nullptr; }
+    musica_pipeline* pl = nullptr;
+    try {
+        pl = new musica_pipeline();
+        pl->depth = depth; pl->steps = 0; pl->windows = 0;
+        for (float& w : pl->window_ms) w = 0.0f;
+        musica_params q = *params;
+        if (depth > 1) q.flags |= MUSICA_FLAG_LINEAR;
+        const uint32_t n = (depth > 1 && depth < MUSICA_PIPELINE_QUEUES) ? MUSICA_PIPELINE_QUEUES : depth;
+        for (uint32_t k = 0; k < n; k++) {
+            musica_ctx* c = musica_create(&q);
+            if (!c) { musica_pipeline_destroy(pl); return nullptr; }
+            pl->ctx.push_back(c);
+        }
+        return pl;
+    } catch (const std::exception& e) {
+        fail("musica_pipeline_create: %s", e.what());
+    }
+    if (pl) musica_pipeline_destroy(pl);
+    return nullptr;
+}
+
+void musica_pipeline_destroy(musica_pipeline* pl) {
+    if (!pl) return;
+    for (musica_ctx* c : pl->ctx) musica_destroy(c);
+    delete pl;
+}
+
+uint32_t musica_pipeline_depth(const musica_pipeline* pl) { return pl ? pl->depth : 0; }
+
+musica_ctx* musica_pipeline_context(musica_pipeline* pl, uint32_t k) {
+    if (!pl || k >= pl->ctx.size()) { fail("musica_pipeline_context: no context %u", k); return nullptr; }
+    return pl->ctx[k];
+}
+
+int musica_pipeline_upload(musica_pipeline* pl, const uint16_t* pixels) {
+    if (!pl) return fail("musica_pipeline_upload: pipeline is NULL");
+    for (musica_ctx* c : pl->ctx)
+        if (!musica_upload(c, pixels)) return 0;
+    return 1;
+}
+
+int musica_pipeline_prime(musica_pipeline* pl, uint32_t calibration_steps) {
+    if (!pl) return fail("musica_pipeline_prime: pipeline is NULL");
+    ABI_TRY
+    for (int rep = 0; rep < 2; rep++)   // the first step of a context captures its graph, the second replays it
+        if (!pipeline_run(pl->ctx, (uint32_t)pl->ctx.size())) return 0;
+    const uint32_t n = (uint32_t)pl->ctx.size();
+    if (n > pl->depth) {
+        if (calibration_steps < pl->depth) calibration_steps = 3 * pl->depth;
+        uint32_t best = 0;
+        for (uint32_t first = 0; first < n; first++) {
+            std::vector<musica_ctx*> use;
+            for (uint32_t k = 0; k < pl->depth; k++) use.push_back(pl->ctx[(first + k) % n]);
+            if (!pipeline_run(use, pl->depth)) return 0;   // warm this combination
+            float ms = 1e30f;
+            for (int rep = 0; rep < 2; rep++) {
+                const auto t0 = std::chrono::steady_clock::now();
+                if (!pipeline_run(use, calibration_steps)) return 0;
+                const float dt = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() / (float)calibration_steps;
+                if (dt < ms) ms = dt;
+            }
+            if (first < MUSICA_PIPELINE_QUEUES) pl->window_ms[first] = ms;
+            if (ms < pl->window_ms[best]) best = first;
+        }
+        pl->windows = n < MUSICA_PIPELINE_QUEUES ? n : MUSICA_PIPELINE_QUEUES;
+        std::vector<musica_ctx*> keep;
+        for (uint32_t k = 0; k < pl->depth; k++) keep.push_back(pl->ctx[(best + k) % n]);
+        for (musica_ctx* c : pl->ctx) {
+            bool stays = false;
+            for (musica_ctx* q : keep) stays = stays || q == c;
+            if (!stays) musica_destroy(c);
+        }
+        pl->ctx = keep;
+    }
+    pl->steps = 0;
+    return 1;
+    ABI_CATCH("musica_pipeline_prime")
+}
+
+uint32_t musica_pipeline_calibration(const musica_pipeline* pl, float* window_ms) {
+    if (!pl) return 0;
+    if (window_ms)
+        for (uint32_t k = 0; k < pl->windows; k++) window_ms[k] = pl->window_ms[k];
+    return pl->windows;
+}
+
+int musica_pipeline_step(musica_pipeline* pl, const uint16_t* d_pixels) {
+    if (!pl || pl->ctx.empty()) return fail("musica_pipeline_step: no pipeline");
+    musica_ctx* c = pl->ctx[pl->steps % pl->ctx.size()];
+    if (!musica_execute_device(c, d_pixels ? d_pixels : c->d_input)) return 0;
+    pl->steps++;
+    return 1;
+}
+
+musica_ctx* musica_pipeline_last(musica_pipeline* pl) {
+    if (!pl || pl->ctx.empty() || pl->steps == 0) { fail("musica_pipeline_last: no step has been enqueued"); return nullptr; }
+    return pl->ctx[(pl->steps - 1) % pl->ctx.size()];
+}
+
+int musica_pipeline_sync(musica_pipeline* pl) {
+    if (!pl) return fail("musica_pipeline_sync: pipeline is NULL");
+    for (musica_ctx* c : pl->ctx)
+        if (!musica_sync(c)) return 0;
     return 1;
 }
 

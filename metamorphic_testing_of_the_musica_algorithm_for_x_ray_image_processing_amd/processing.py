@@ -151,6 +151,16 @@ ABI = {
     "musica_read_raw": (C.c_int, [C.c_char_p, C.c_uint32, _U16P]),
     "musica_write_bmp_gray": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _U8P]),
     "musica_write_bmp_rgba": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _U8P]),
+    "musica_pipeline_create": (_VP, [C.POINTER(Params), C.c_uint32]),
+    "musica_pipeline_destroy": (None, [_VP]),
+    "musica_pipeline_depth": (C.c_uint32, [_VP]),
+    "musica_pipeline_context": (_VP, [_VP, C.c_uint32]),
+    "musica_pipeline_upload": (C.c_int, [_VP, _U16P]),
+    "musica_pipeline_prime": (C.c_int, [_VP, C.c_uint32]),
+    "musica_pipeline_calibration": (C.c_uint32, [_VP, _F32P]),
+    "musica_pipeline_step": (C.c_int, [_VP, _VP]),
+    "musica_pipeline_last": (_VP, [_VP]),
+    "musica_pipeline_sync": (C.c_int, [_VP]),
     "musica_last_error": (C.c_char_p, []),
     "musica_abi_version": (C.c_uint32, []),
     "musica_device_count": (C.c_int, []),
@@ -195,9 +205,21 @@ class MusicaProcessing:
         self._lib = load_library()
         self._device = int(device)
         self._h = None
+        self._owned = True
         self.imageSize = 0
         self.pyramidLevels = 0
         self.batch = 1
+
+    @classmethod
+    def _borrow(cls, handle, device=0):
+        """A view of a context something else owns (a MusicaPipeline): every getter works, cleanup() leaves it alone."""
+        self = cls(device)
+        self._h = handle
+        self._owned = False
+        self.imageSize = self._lib.musica_get_image_size(handle)
+        self.pyramidLevels = self._lib.musica_get_levels(handle)
+        self.batch = self._lib.musica_get_batch(handle)
+        return self
 
     # ---- the reference's interface -------------------------------------------------
     def init(self, imageSize, outImageViews=None, levels=0, batch=1, flags=0):
@@ -242,7 +264,8 @@ class MusicaProcessing:
     def cleanup(self):
         """bool cleanup() — src/vk_processing.cpp:2647-2651."""
         if self._h:
-            self._lib.musica_destroy(self._h)
+            if self._owned:
+                self._lib.musica_destroy(self._h)
             self._h = None
         return True
 
@@ -517,6 +540,67 @@ class MusicaProcessing:
             self.device_free(d_in)
             self.device_free(d_out)
         return us.value, (cus.value if copy_ceiling else None)
+
+
+class MusicaPipeline:
+    """The C ABI's steps-in-flight object (musica_pipeline_*, include/musica.h): `depth` one-stream contexts of one GPU whose
+    steps alternate, with the choice of hardware queues made by musica_pipeline_prime(). batch.ShardPipeline is the same
+    thing written in Python on top of MusicaProcessing (and is what bench.py uses); this class is the native one."""
+
+    def __init__(self, imageSize, levels=0, batch=1, depth=3, flags=0, device=0):
+        self._lib = load_library()
+        p = Params(int(imageSize), int(levels), int(batch), int(device), int(flags))
+        self._p = self._lib.musica_pipeline_create(C.byref(p), int(depth))
+        if not self._p:
+            raise RuntimeError("musica_pipeline_create failed: " + last_error())
+        self._device = int(device)
+        self.depth = int(depth)
+
+    def _ok(self, rc, what):
+        if rc != 1:
+            raise RuntimeError("%s failed: %s" % (what, last_error()))
+
+    def upload(self, images):
+        px = np.ascontiguousarray(images, dtype=np.uint16)
+        self._ok(self._lib.musica_pipeline_upload(self._p, px.ctypes.data_as(_U16P)), "musica_pipeline_upload")
+
+    def prime(self, calibration_steps=0):
+        self._ok(self._lib.musica_pipeline_prime(self._p, int(calibration_steps)), "musica_pipeline_prime")
+
+    def calibration(self):
+        """{first context of the window: ms per step} of the windows prime() timed ({} when there was nothing to choose)."""
+        ms = np.zeros(4, dtype=np.float32)
+        n = self._lib.musica_pipeline_calibration(self._p, _f32p(ms))
+        return {k: float(ms[k]) for k in range(n)}
+
+    def context(self, k):
+        h = self._lib.musica_pipeline_context(self._p, int(k))
+        if not h:
+            raise IndexError(last_error())
+        return MusicaProcessing._borrow(h, self._device)
+
+    def step(self, d_pixels=None):
+        self._ok(self._lib.musica_pipeline_step(self._p, d_pixels), "musica_pipeline_step")
+
+    def last(self):
+        h = self._lib.musica_pipeline_last(self._p)
+        if not h:
+            raise RuntimeError(last_error())
+        return MusicaProcessing._borrow(h, self._device)
+
+    def sync(self):
+        self._ok(self._lib.musica_pipeline_sync(self._p), "musica_pipeline_sync")
+
+    def cleanup(self):
+        if self._p:
+            self._lib.musica_pipeline_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass
 
 
 def read_raw(path, image_size):

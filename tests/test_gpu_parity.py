@@ -696,3 +696,49 @@ def test_histogram_plots_equal_the_oracles(ob, n, levels, seed, batch):
         assert (c[..., :3] == [0, 0, 255]).all(axis=-1).sum() >= 256                                # the curve, one texel per column
         assert (c[..., :3] == [0, 255, 0]).all(axis=-1).sum() >= 127                                # the ta column
     p.cleanup()
+
+
+def test_native_pipeline_of_the_c_abi(ob):
+    """musica_pipeline_* (the C ABI's steps-in-flight object): create with depth 3 -> four one-stream contexts, prime() times the
+    four windows of hardware queues and keeps three contexts, 8 overlapping steps; the context of the last step and the two
+    beside it equal the oracle bit for bit, the step counter walks the kept contexts in order, and depth 1 is a plain context."""
+    n, levels, b = 520, 5, 2
+    px = np.stack([phantom(n, 2000 + k) for k in range(b)])
+    want = [ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[k]) for k in range(b)]
+    pl = mp.MusicaPipeline(n, levels=levels, batch=b, depth=3)
+    pl.upload(px)
+    pl.prime(6)
+    cal = pl.calibration()
+    assert sorted(cal) == [0, 1, 2, 3] and all(0.0 < v < 50.0 for v in cal.values())
+    handles = [pl.context(k)._h for k in range(3)]
+    assert len(set(handles)) == 3
+    with pytest.raises(IndexError):
+        pl.context(3)
+    for s in range(8):
+        pl.step()
+        assert pl.last()._h == handles[s % 3]
+    pl.sync()
+    for k in range(3):
+        c = pl.context(k)
+        assert c.batch == b and c.pyramidLevels == levels
+        for i in range(b):
+            _compare_all(c, want[i], ob, idx=i, tag="pipeline context %d image %d: " % (k, i))
+    # a caller-owned device buffer as the step's input
+    other = np.stack([phantom(n, 2100 + k) for k in range(b)])
+    c0 = pl.context(0)
+    d = c0.device_alloc(other.nbytes)
+    c0.h2d(d, other)
+    pl.step(d)                       # step 8 -> context 8 % 3 = 2
+    pl.sync()
+    o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(other[1])
+    _same(pl.last().image(mp.IMG_GRADED, 0, 1), o.image(ob.IMG_GRADED), "graded (caller-owned input through the pipeline)")
+    c0.device_free(d)
+    pl.cleanup()
+    one = mp.MusicaPipeline(n, levels=levels, batch=1, depth=1)
+    one.upload(px[:1])
+    one.prime()
+    assert one.calibration() == {}
+    one.step()
+    one.sync()
+    _same(one.last().image(mp.IMG_GRADED), want[0].image(ob.IMG_GRADED), "graded (depth 1)")
+    one.cleanup()
