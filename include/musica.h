@@ -278,6 +278,11 @@ int musica_pipeline_prime(musica_pipeline* p, uint32_t calibration_steps);
 uint32_t musica_pipeline_calibration(const musica_pipeline* p, float* window_ms /* [MUSICA_PIPELINE_QUEUES] or NULL */);
 /* Enqueue one step on the next context: d_pixels (device memory, 16-byte aligned) or, when NULL, that context's own input. */
 int musica_pipeline_step(musica_pipeline* p, const uint16_t* d_pixels);
+/* The same from host memory (batch x N x N uint16): the host-to-device copy is enqueued on the next context's stream in front of
+ * its step, i.e. it runs under the kernels of the other contexts (what replaces VulkanState::loadDataToImage's staging upload
+ * with three queue-idle waits, src/vk_state.cpp:313-342). `pixels` must stay valid until that context is synchronised or has
+ * been handed a later step; pinned memory (musica_host_alloc) moves at the PCIe rate. */
+int musica_pipeline_step_host(musica_pipeline* p, const uint16_t* pixels);
 /* The context the most recent step was enqueued on. */
 musica_ctx* musica_pipeline_last(musica_pipeline* p);
 int musica_pipeline_sync(musica_pipeline* p);

@@ -1696,6 +1696,21 @@ int musica_pipeline_step(musica_pipeline* pl, const uint16_t* d_pixels) {
     return 1;
 }
 
+// Host pixels in: the copy into the next context's input buffer is enqueued on that context's stream in front of its step, so it
+// runs under the kernels of the other contexts' steps (the reference uploads through a staging buffer with three queue-idle
+// waits per image, VulkanState::loadDataToImage, src/vk_state.cpp:313-342). `pixels` must stay valid until that context is
+// synchronised or has been handed its next step; pinned memory (musica_host_alloc) moves at the PCIe rate.
+int musica_pipeline_step_host(musica_pipeline* pl, const uint16_t* pixels) {
+    if (!pl || pl->ctx.empty()) return fail("musica_pipeline_step_host: no pipeline");
+    if (!pixels) return fail("musica_pipeline_step_host: pixels is NULL");
+    musica_ctx* c = pl->ctx[pl->steps % pl->ctx.size()];
+    if (hipSetDevice(c->p.device) != hipSuccess) return fail("musica_pipeline_step_host: hipSetDevice failed");
+    HIP_OK(hipMemcpyAsync(c->d_input, pixels, (size_t)c->B * c->N * c->N * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    if (!musica_execute_device(c, c->d_input)) return 0;
+    pl->steps++;
+    return 1;
+}
+
 musica_ctx* musica_pipeline_last(musica_pipeline* pl) {
     if (!pl || pl->ctx.empty() || pl->steps == 0) { fail("musica_pipeline_last: no step has been enqueued"); return nullptr; }
     return pl->ctx[(pl->steps - 1) % pl->ctx.size()];

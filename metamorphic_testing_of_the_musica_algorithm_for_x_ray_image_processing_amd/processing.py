@@ -159,6 +159,7 @@ ABI = {
     "musica_pipeline_prime": (C.c_int, [_VP, C.c_uint32]),
     "musica_pipeline_calibration": (C.c_uint32, [_VP, _F32P]),
     "musica_pipeline_step": (C.c_int, [_VP, _VP]),
+    "musica_pipeline_step_host": (C.c_int, [_VP, _U16P]),
     "musica_pipeline_last": (_VP, [_VP]),
     "musica_pipeline_sync": (C.c_int, [_VP]),
     "musica_last_error": (C.c_char_p, []),
@@ -581,6 +582,12 @@ class MusicaPipeline:
 
     def step(self, d_pixels=None):
         self._ok(self._lib.musica_pipeline_step(self._p, d_pixels), "musica_pipeline_step")
+
+    def step_host(self, images):
+        """One step on host pixels (uint16 array, C-contiguous; keep it alive until the pipeline is synchronised)."""
+        if not (isinstance(images, np.ndarray) and images.dtype == np.uint16 and images.flags["C_CONTIGUOUS"]):
+            raise TypeError("step_host needs a C-contiguous uint16 array (it is read asynchronously)")
+        self._ok(self._lib.musica_pipeline_step_host(self._p, images.ctypes.data_as(_U16P)), "musica_pipeline_step_host")
 
     def last(self):
         h = self._lib.musica_pipeline_last(self._p)

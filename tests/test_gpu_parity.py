@@ -742,3 +742,30 @@ def test_native_pipeline_of_the_c_abi(ob):
     one.sync()
     _same(one.last().image(mp.IMG_GRADED), want[0].image(ob.IMG_GRADED), "graded (depth 1)")
     one.cleanup()
+
+
+def test_native_pipeline_from_host_pixels(ob):
+    """musica_pipeline_step_host: every step brings its own pixels from (pinned) host memory, the copy in front of the step on its
+    context's stream. Six steps with six different batches over three contexts: the last three are what the contexts hold."""
+    n, levels, b = 520, 5, 2
+    pl = mp.MusicaPipeline(n, levels=levels, batch=b, depth=3)
+    c0 = pl.context(0)
+    pl.upload(np.stack([phantom(n, 3000 + k) for k in range(b)]))
+    pl.prime(6)
+    c0 = pl.context(0)
+    batches = [np.stack([phantom(n, 3100 + 10 * s + k) for k in range(b)]) for s in range(6)]
+    hbufs = [c0.host_alloc(batches[0].shape) for _ in range(6)]
+    for hb, px in zip(hbufs, batches):
+        hb[...] = px
+    for s in range(6):
+        pl.step_host(hbufs[s])
+    pl.sync()
+    for k in range(3):                      # context k ran steps k and k + 3
+        for i in range(b):
+            o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(batches[3 + k][i])
+            _compare_all(pl.context(k), o, ob, idx=i, tag="host step %d image %d: " % (3 + k, i))
+    with pytest.raises(TypeError):
+        pl.step_host(batches[0].astype(np.int32))
+    for hb in hbufs:
+        c0.host_free(hb)
+    pl.cleanup()
