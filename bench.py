@@ -367,7 +367,7 @@ def main():
             cold_us, copy_us = proc.k_reduce_cold(4096, nbuf=COLD_BUFFERS, iters=COLD_ITERS)
             warm_us = proc.k_reduce_timed(4096, batch=1, iters=200)
             gb = lambda us: round(b4096 / (us * 1e-6) / 1e9, 1)
-            roofline = {"kernel": "k_reduce_fast_pf (fused 5-tap smooth + 2x downsample) stand-alone on 4096x4096 f32, %d back-to-back launches rotating over "
+            roofline = {"kernel": "k_reduce_dma (fused 5-tap smooth + 2x downsample, LDS-DMA tiles) stand-alone on 4096x4096 f32, %d back-to-back launches rotating over "
                                   "%d distinct input / output planes (%d MB footprint > 256 MiB Infinity Cache: every launch reads from HBM)"
                                   % (COLD_ITERS, COLD_BUFFERS, COLD_BUFFERS * b4096 // 1000000),
                         "bound": "hbm", "achieved": gb(cold_us), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb(cold_us) / HBM_PEAK_GBS, 4),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MUSICA_ABI_VERSION 1
+#define MUSICA_ABI_VERSION 2
 
 /* Hard-coded constants of the reference. */
 #define MUSICA_MAX_LEVELS 16          /* reference: 12 + 1 clear buffers, vk_processing.h:67 */
@@ -345,10 +345,9 @@ int musica_k_reduce_timed(musica_ctx* ctx, const float* d_in, uint32_t side, uin
 
 /* The same measurement from HBM rather than from the 256 MiB Infinity Cache: launch i uses input plane
  * d_in + (i % nbuf) * in_pitch * side and output plane d_out + (i % nbuf) * out_pitch * ceil(side/2), so with
- * nbuf * 5 * side^2 bytes well above 256 MiB no launch finds its input (or the lines of its output) on the die.
- * rows_per_wave = 0 takes the library's own launch geometry (the one the pipeline uses). */
+ * nbuf * 5 * side^2 bytes well above 256 MiB no launch finds its input (or the lines of its output) on the die. */
 int musica_k_reduce_timed_rot(musica_ctx* ctx, const float* d_in, uint32_t side, uint32_t in_pitch, float* d_out,
-                              uint32_t out_pitch, uint32_t nbuf, uint32_t iters, uint32_t rows_per_wave, double* mean_us);
+                              uint32_t out_pitch, uint32_t nbuf, uint32_t iters, double* mean_us);
 /* Measurement aid, not on the product path: a plain streaming kernel with the metric kernel's traffic shape
  * (reads side^2 f32 with 16-byte loads, writes (side/2)^2 f32 with 16-byte stores, no halo, no arithmetic to
  * speak of), timed the same rotating way — the ceiling `roofline.frac` can be read against. side % 8 == 0,

@@ -88,7 +88,8 @@ __device__ __forceinline__ void load_row(RowR& r, const Buf& b, uint32_t row_off
 }
 
 // One output row from its five input rows (vertical pass in registers, horizontal pass with the
-// neighbour columns taken from the adjacent lanes).
+// neighbour columns taken from the adjacent lanes). AUX: cache policy of the store (0 plain, 2 non-temporal).
+template <int AUX = 0>
 __device__ __forceinline__ void reduce_row(const RowR& r0, const RowR& r1, const RowR& r2, const RowR& r3, const RowR& r4,
                                            const LaneCfg& g, const Buf& ob, uint32_t out_off) {
     float v[8];
@@ -106,64 +107,100 @@ __device__ __forceinline__ void reduce_row(const RowR& r0, const RowR& r1, const
     }
     if (g.last_active) vr0 = v[6];         // column S -> S-2 (img_smooth.comp:12)
     else if (g.lane63) vr0 = vhr;
-    float4 o;
+    v4f o;
     o.x = chain5(vl6, vl7, v[0], v[1], v[2]);
     o.y = chain5(v[0], v[1], v[2], v[3], v[4]);
     o.z = chain5(v[2], v[3], v[4], v[5], v[6]);
     o.w = chain5(v[4], v[5], v[6], v[7], vr0);
-    bstore4(ob, g.coff + out_off, o);      // output columns c/2 .. c/2+3; dropped for lanes right of the image
+    llvm_buffer_store_v4f32(o, ob.r, (int)(g.coff + out_off), 0, AUX);   // output columns c/2 .. c/2+3; dropped for lanes right of the image
 }
 
-// grid: x = strips, y = ceil(segments / 4), z = batch. One wavefront = one (strip, segment).
-// Software-pipelined: one output row per trip, and the input rows of the next D trips are already
-// requested while trip k is computed, so a wavefront always has 2*D rows (4*D KiB) of loads in flight
-// behind its arithmetic. (Rows-per-trip, rotating-register and LDS-tiled forms of this kernel were
-// measured slower at 4096^2 in round 1 and live in the git history, not here.)
-// TAG only separates the launch sites in profiler output (one symbol per site, so rocprofv3's
-// per-kernel averages are not a mix of pyramid levels): 0 = level 0 of the pipeline, 1 = levels >= 1,
-// 2 = stand-alone musica_k_reduce, 3 = init-time autotune, 4 = stand-alone rotating over distinct planes (musica_k_reduce_timed_rot).
-template <int D, int TAG>
-__global__ __launch_bounds__(kBlockThreads) void k_reduce_fast_pf(const float* __restrict__ in, float* __restrict__ out,
-                                                                  int S, int pitch, size_t in_plane, int So, int opitch,
-                                                                  size_t out_plane, int rows_per_wave, int swz) {
+// ---- the metric kernel: img_smooth.comp:18-50 + img_downsample.comp:10-20 of an f32 level -----------------------
+// One 256-thread workgroup owns a tile of 512 input columns x kDmaRows output rows. Its 2 * kDmaRows + 3 input rows are
+// brought in by LDS-DMA (`buffer_load_dwordx4 ... lds`: 1 KiB per wave-instruction straight from HBM / L2 into LDS, no
+// VGPR destination and no register write-back), all of them requested before anything else happens — the four
+// wavefronts issue the 2 KiB rows piecewise round-robin — plus one 4-byte DMA for the three halo columns (c0-2, c0-1,
+// c0+512) of every row. Each wavefront then waits for its own DMAs, the workgroup meets at ONE barrier, and every
+// wavefront computes one output row: five 16-byte-pair LDS reads per lane, the vertical 5-tap pass in registers, the
+// horizontal pass with its 2 + 1 neighbour columns from the adjacent lanes by DPP wave shifts (halo columns on lane 0 /
+// 63), one non-temporal 16-byte store per lane (the output is not read again by this launch: a plain store leaves the
+// lines dirty in the XCD's L2 and their write-back competes with the incoming rows — 18.7 -> 15.9 us at 4096^2).
+// 22 KiB of LDS per workgroup: 7 workgroups = 154 KiB of rows in flight per CU, and the grid is fine-grained enough
+// (4096 workgroups at 4096^2) that the tail of the launch is short. Measured from HBM on MI355X (DESIGN.md §6,
+// profiles/r03_*): 4096^2 15.9 us = 0.66 of 8 TB/s (register-staged march of rounds 1-2: 19.3; a plain copy of the same
+// traffic shape: 16.0, with non-temporal stores 15.4), 8192^2 55.3 us = 0.76 (march 65.6, copy 59.3).
+// Rows the mirror sends outside [0, S) (only when S < 3 could that happen; the fast path needs S >= 8) do not occur; the
+// last tile of an image whose So is not a multiple of kDmaRows re-requests valid rows and drops the surplus output rows.
+// TAG only separates the launch sites in profiler output: 0 / 1 = level 0 / levels >= 1 of a pipeline that does not fuse
+// reduce + band, 2 = stand-alone musica_k_reduce, 4 = stand-alone rotating over distinct planes (musica_k_reduce_timed_rot).
+constexpr int kDmaRows = 4;                           // output rows per workgroup (one per wavefront)
+constexpr int kDmaInRows = 2 * kDmaRows + 3;          // input rows of a tile
+constexpr int kDmaPieces = 2 * kDmaInRows;            // 1 KiB pieces (half rows)
+constexpr int kDmaPiecesPerWave = (kDmaPieces + kWavesPerBlock - 1) / kWavesPerBlock;
+static_assert(kDmaRows == kWavesPerBlock && kDmaInRows * 3 <= 64, "tile shape");
+
+// M0 = LDS byte address the wave-instruction writes to (wave-uniform); lane l lands at M0 + 16 l (dwordx4) / M0 + 4 l (dword).
+// An asm load is invisible to hipcc's s_waitcnt bookkeeping: the kernel waits with its own vmcnt(0) below.
+// (M0 is compiler-reserved: it is saved and restored inside the statement that changes it.)
+__device__ __forceinline__ void dma16(const Buf& b, uint32_t voff, uint32_t lds_byte) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(b.r) : "memory");
+}
+__device__ __forceinline__ void dma4(const Buf& b, uint32_t voff, uint32_t lds_byte) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(b.r) : "memory");
+}
+
+template <int TAG>
+__global__ __launch_bounds__(kBlockThreads) void k_reduce_dma(const float* __restrict__ in, float* __restrict__ out,
+                                                              int S, int pitch, size_t in_plane, int So, int opitch,
+                                                              size_t out_plane, int swz) {
+    __shared__ __attribute__((aligned(16))) float tile_s[kDmaInRows * kStripCols + 64];
     const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const Tile tile = xcd_tile(swz);
-    const int seg = __builtin_amdgcn_readfirstlane((int)(tile.segblock * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
-    const int yo0 = seg * rows_per_wave;
-    if (yo0 >= So) return;  // wave-uniform
-    const int yo1 = min(yo0 + rows_per_wave, So);
+    const int yo0 = tile.segblock * kDmaRows;
     const Buf ib = make_buf(in + (size_t)blockIdx.z * in_plane, in_plane * 4);
     const Buf ob = make_buf(out + (size_t)blockIdx.z * out_plane, out_plane * 4);
     const LaneCfg g = make_cfg(tile.strip, lane, S);
+    const int c0 = tile.strip * kStripCols;
     const int hi = S - 1;
     const uint32_t rb = (uint32_t)pitch * 4u, orb = (uint32_t)opitch * 4u;
-    // Odd segments march upwards, even ones downwards: two vertically adjacent wavefronts then touch
-    // their 3 shared halo rows at the same moment (both at their start, or both at their end), so the
-    // second reader hits the XCD's L2 instead of fetching the rows again (rocprofv3 FETCH_SIZE: -25 %).
-    // Window slot k holds input row 2*yo + dir*(k-2); chain5 always gets the rows in top-to-bottom order.
-    const int dir = (seg & 1) ? -1 : 1;
-    const int n = yo1 - yo0;
-    const int yfirst = dir > 0 ? yo0 : yo1 - 1;
-    RowR w[5 + 2 * D];
-    load_row(w[0], ib, (uint32_t)mirror_idx(2 * yfirst - 2 * dir, hi) * rb, g);
-    load_row(w[1], ib, (uint32_t)mirror_idx(2 * yfirst - dir, hi) * rb, g);
-    load_row(w[2], ib, (uint32_t)(2 * yfirst) * rb, g);
-#pragma unroll
-    for (int d = 0; d < D; d++) {  // trips 0 .. D-1 (clamped: rows past the segment are requested, never consumed)
-        const int ya = yfirst + dir * min(d, n - 1);
-        load_row(w[3 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + dir, hi) * rb, g);
-        load_row(w[4 + 2 * d], ib, (uint32_t)mirror_idx(2 * ya + 2 * dir, hi) * rb, g);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)tile_s;   // LDS byte address of the tile (low half of the flat address)
+    // local row k of the tile = input row mirror(2 * yo0 - 2 + k) (img_smooth.comp:10-16), kept inside the image
+    // halo columns of every row, one dword each: entry 3 k + j, j = 0: c0-2, 1: c0-1, 2: c0+512 (wavefront 0 only)
+    if (wave == 0) {
+        const int k = lane / 3, j = lane - 3 * k;
+        const int y = min(max(mirror_idx(2 * yo0 - 2 + min(k, kDmaInRows - 1), hi), 0), hi);
+        const int col = j == 0 ? c0 - 2 : j == 1 ? c0 - 1 : c0 + kStripCols;
+        const bool ok = k < kDmaInRows && col >= 0 && col < S;
+        dma4(ib, ok ? (uint32_t)y * rb + (uint32_t)col * 4u : kOob, lds0 + (uint32_t)(kDmaInRows * kStripCols) * 4u);
     }
-    for (int t = 0; t < n; t++) {
-        const int yo = yfirst + dir * t;
-        const int yn = yfirst + dir * min(t + D, n - 1);
-        load_row(w[3 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + dir, hi) * rb, g);
-        load_row(w[4 + 2 * D], ib, (uint32_t)mirror_idx(2 * yn + 2 * dir, hi) * rb, g);
-        if (dir > 0) reduce_row(w[0], w[1], w[2], w[3], w[4], g, ob, (uint32_t)yo * orb);  // wave-uniform
-        else reduce_row(w[4], w[3], w[2], w[1], w[0], g, ob, (uint32_t)yo * orb);
+    const uint32_t lane_off = (uint32_t)(c0 + lane * 4) * 4u;   // a piece = 256 columns, 4 per lane
 #pragma unroll
-        for (int i = 0; i < 3 + 2 * D; i++) w[i] = w[i + 2];
+    for (int i = 0; i < kDmaPiecesPerWave; i++) {
+        const int q = min(i * kWavesPerBlock + wave, kDmaPieces - 1);   // a wave without a last piece repeats the tile's last one
+        const int k = q >> 1, half = q & 1;
+        const int y = min(max(mirror_idx(2 * yo0 - 2 + k, hi), 0), hi);
+        const bool ok = c0 + half * 256 + lane * 4 < S;
+        dma16(ib, ok ? (uint32_t)y * rb + lane_off + (uint32_t)half * 1024u : kOob, lds0 + (uint32_t)(k * kStripCols + half * 256) * 4u);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float* hal = tile_s + kDmaInRows * kStripCols;
+    RowR w[5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const int k = 2 * wave + r;
+        const float4 a = *reinterpret_cast<const float4*>(tile_s + k * kStripCols + lane * 8);
+        const float4 b = *reinterpret_cast<const float4*>(tile_s + k * kStripCols + lane * 8 + 4);
+        w[r].v[0] = a.x; w[r].v[1] = a.y; w[r].v[2] = a.z; w[r].v[3] = a.w; w[r].v[4] = b.x; w[r].v[5] = b.y; w[r].v[6] = b.z; w[r].v[7] = b.w;
+        w[r].hl0 = hal[3 * k]; w[r].hl1 = hal[3 * k + 1]; w[r].hr = hal[3 * k + 2];
+    }
+    const int yo = yo0 + wave;
+    if (yo < So) reduce_row<2>(w[0], w[1], w[2], w[3], w[4], g, ob, (uint32_t)yo * orb);   // wave-uniform
 }
 
 // ---- level 0 straight from the raw pixels ------------------------------------------------------
@@ -230,7 +267,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_u16_pf(const uint16_t*
     const U16Cfg u = make_u16cfg(g);
     const int hi = S - 1;
     const uint32_t rb = (uint32_t)S * 2u, orb = (uint32_t)opitch * 4u;
-    const int dir = (seg & 1) ? -1 : 1;  // see k_reduce_fast_pf
+    // Odd segments march upwards, even ones downwards: two vertically adjacent wavefronts then touch their 3 shared halo rows
+    // at the same moment, so the second reader hits the XCD's L2. Window slot k holds input row 2*yo + dir*(k-2); chain5
+    // always gets the rows in top-to-bottom order.
+    const int dir = (seg & 1) ? -1 : 1;
     const int n = yo1 - yo0;
     const int yfirst = dir > 0 ? yo0 : yo1 - 1;
     RowR w0, w1, w2, w3, w4;
@@ -968,13 +1008,16 @@ static const dim3 kGenericBlock(32, 8, 1);
 
 static inline bool fast_ok(int S) { return S >= 8 && (S % 8) == 0; }
 
-// tag: launch site (see k_reduce_fast_pf)
-void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch,
-                   int rows_per_wave, bool force_generic, int tag) {
+// tag: launch site (see k_reduce_dma)
+void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, bool force_generic, int tag) {
     if (fast_ok(li.S) && !force_generic) {
-        const dim3 grid = stream_grid(li.S, lo.S, rows_per_wave, batch);
-        auto* kern = tag == 0 ? k_reduce_fast_pf<1, 0> : tag == 1 ? k_reduce_fast_pf<1, 1> : tag == 2 ? k_reduce_fast_pf<1, 2> : tag == 3 ? k_reduce_fast_pf<1, 3> : k_reduce_fast_pf<1, 4>;
-        hipLaunchKernelGGL(kern, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, rows_per_wave, xcd_swizzle_on());
+        const int strips = (li.S + kStripCols - 1) / kStripCols;
+        const dim3 grid(strips, (lo.S + kDmaRows - 1) / kDmaRows, batch);
+        // 8 k strips: workgroup id % 8 == strip % 8 already gives every strip one XCD, tile above tile in dispatch order; otherwise
+        // the XCD-aware mapping does (2048^2: 6.0 -> 5.05 us; it costs 1.5 us at 4096^2 where the plain mapping has that property)
+        const int swz = (strips % 8) != 0 ? xcd_swizzle_on() : 0;
+        auto* kern = tag == 0 ? k_reduce_dma<0> : tag == 1 ? k_reduce_dma<1> : tag == 2 ? k_reduce_dma<2> : k_reduce_dma<4>;
+        hipLaunchKernelGGL(kern, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, swz);
     } else {
         hipLaunchKernelGGL(k_reduce_generic, generic_grid(lo.S, batch), kGenericBlock, 0, st, in, out, li.S, li.pitch,
                            li.plane, lo.S, lo.pitch, lo.plane);

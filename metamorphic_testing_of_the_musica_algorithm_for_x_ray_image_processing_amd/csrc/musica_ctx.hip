@@ -198,10 +198,6 @@ static int pick_rows(int dflt, int min_rows, int S, int rows_total, int batch, i
     }
     return rpw < min_rows ? min_rows : rpw;
 }
-// Stand-alone launches of the metric kernel (no autotune behind them): at least four wavefronts per SIMD. Measured from HBM
-// (rotating buffers): 4096^2 18.6 us at 4 rows per wavefront against 20.8 at 8; 8192^2 best at 16 rows (4096 wavefronts either way).
-static const int kStandaloneMinWaves = 4096;
-
 // How many independent groups the batch is cut into: MUSICA_GROUPS, default 1. Measured on MI355X at
 // 8 x 2048 x 2048 ("Image groups"): 1 group 0.565 ms, 2 groups 0.586 ms, 4 groups 0.78 ms per step —
 // the groups start in lockstep, so their small kernels meet each other instead of the other group's
@@ -589,7 +585,7 @@ static void run_reduce_level(musica_ctx* c, int i, int rows) {
         launch_reduce_u16(c->cur, c->cur_input, c->lv[0], c->d_down[0], c->lv[1], c->B, rows, c->d_minmax, c->min_chain_exact);
         return;
     }
-    launch_reduce(c->cur, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, rows, c->generic, c->tuning ? 3 : (i == 0 ? 0 : 1));
+    launch_reduce(c->cur, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, c->generic, i == 0 ? 0 : 1);   // one fixed tile shape: `rows` only steers the uint16 form
 }
 // reduce + band of a level in one launch
 static bool rb_level(const musica_ctx* c, int i) {
@@ -927,7 +923,7 @@ static void autotune(musica_ctx* c) {
         static const int cand_rb[] = {4, 8, 16, 32, 64};
         struct { int* slot; const int* cand; int ncand; void (*fn)(musica_ctx*, int, int); bool use; } jobs[5] = {
             {&c->rows_rb[i], cand_rb, 5, run_reduce_band, rb_level(c, i)},
-            {&c->rows_reduce[i], cand_reduce, 5, run_reduce_level, !rb_level(c, i)},
+            {&c->rows_reduce[i], cand_reduce, 5, run_reduce_level, !rb_level(c, i) && i == 0 && c->fuse_u16},
             {&c->rows_band[i], cand_pair, 4, run_band_level, !rb_level(c, i)},
             {&c->rows_expand[i], cand_pair, 4, run_expand_level, true},
             {i <= MUSICA_CNR_LEVEL ? &c->rows_sdev[i] : nullptr, cand_sdev, 3, run_sdev_level, i <= MUSICA_CNR_LEVEL && env_int("MUSICA_TUNE_SDEV", 1) != 0},
@@ -1457,7 +1453,7 @@ int musica_k_reduce(musica_ctx* c, const float* d_in, uint32_t side, uint32_t in
     CHECK_CTX(c);
     LevelDesc li, lo;
     if (!reduce_descs(side, in_pitch, out_pitch, &li, &lo)) return 0;
-    launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, pick_rows(c->reduce_rows, 1, li.S, lo.S, (int)batch, kStandaloneMinWaves), c->generic, 2);
+    launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, c->generic, 2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e));
     return 1;
@@ -1487,12 +1483,11 @@ int musica_k_reduce_timed(musica_ctx* c, const float* d_in, uint32_t side, uint3
     LevelDesc li, lo;
     if (!reduce_descs(side, in_pitch, out_pitch, &li, &lo)) return 0;
     if (iters < 1) iters = 1;
-    const int rpw = pick_rows(c->reduce_rows, 1, li.S, lo.S, (int)batch, kStandaloneMinWaves);
     hipEvent_t a, b;
     HIP_OK(hipEventCreate(&a));
     HIP_OK(hipEventCreate(&b));
     HIP_OK(hipEventRecord(a, c->stream));
-    for (uint32_t i = 0; i < iters; i++) launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, rpw, c->generic, 2);
+    for (uint32_t i = 0; i < iters; i++) launch_reduce(c->stream, d_in, li, d_out, lo, (int)batch, c->generic, 2);
     HIP_OK(hipEventRecord(b, c->stream));
     HIP_OK(hipEventSynchronize(b));
     float ms = 0.f;
@@ -1504,19 +1499,18 @@ int musica_k_reduce_timed(musica_ctx* c, const float* d_in, uint32_t side, uint3
 }
 
 int musica_k_reduce_timed_rot(musica_ctx* c, const float* d_in, uint32_t side, uint32_t in_pitch, float* d_out, uint32_t out_pitch, uint32_t nbuf,
-                              uint32_t iters, uint32_t rows_per_wave, double* mean_us) {
+                              uint32_t iters, double* mean_us) {
     CHECK_CTX(c);
     LevelDesc li, lo;
     if (!reduce_descs(side, in_pitch, out_pitch, &li, &lo)) return 0;
     if (iters < 1) iters = 1;
     if (nbuf < 1) nbuf = 1;
-    const int rpw = rows_per_wave ? (int)rows_per_wave : pick_rows(c->reduce_rows, 1, li.S, lo.S, 1, kStandaloneMinWaves);
     hipEvent_t a, b;
     HIP_OK(hipEventCreate(&a));
     HIP_OK(hipEventCreate(&b));
     HIP_OK(hipEventRecord(a, c->stream));
     for (uint32_t i = 0; i < iters; i++)
-        launch_reduce(c->stream, d_in + (size_t)(i % nbuf) * li.plane, li, d_out + (size_t)(i % nbuf) * lo.plane, lo, 1, rpw, c->generic, 4);
+        launch_reduce(c->stream, d_in + (size_t)(i % nbuf) * li.plane, li, d_out + (size_t)(i % nbuf) * lo.plane, lo, 1, c->generic, 4);
     HIP_OK(hipEventRecord(b, c->stream));
     HIP_OK(hipEventSynchronize(b));
     float ms = 0.f;

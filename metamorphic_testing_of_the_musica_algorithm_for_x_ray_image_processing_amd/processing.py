@@ -142,7 +142,7 @@ ABI = {
     "musica_k_reduce": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32]),
     "musica_selftest_exact_math": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "musica_k_reduce_timed": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
-    "musica_k_reduce_timed_rot": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+    "musica_k_reduce_timed_rot": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     "musica_k_copy41_timed_rot": (C.c_int, [_VP, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     "musica_device_alloc": (_VP, [_VP, C.c_size_t]),
     "musica_device_free": (None, [_VP, _VP]),
@@ -521,7 +521,7 @@ class MusicaProcessing:
         return us.value
 
 
-    def k_reduce_cold(self, side, nbuf=8, iters=64, rows_per_wave=0, copy_ceiling=True, seed=0):
+    def k_reduce_cold(self, side, nbuf=8, iters=64, copy_ceiling=True, seed=0):
         """Mean microseconds per launch of the metric kernel on side x side f32 images rotating over `nbuf` distinct
         input / output planes (nbuf * 5 * side^2 bytes must exceed the 256 MiB Infinity Cache for an HBM number),
         and of the copy-shaped ceiling kernel timed the same way. Returns (kernel_us, copy_us or None)."""
@@ -533,7 +533,7 @@ class MusicaProcessing:
                 self.h2d(d_in + k * side * side * 4, rng.random((side, side), dtype=np.float32))
             us, cus = C.c_double(), C.c_double()
             for it in (nbuf, iters):    # first pass: warm-up (code object, TLB)
-                self._ok(self._lib.musica_k_reduce_timed_rot(self._h, d_in, side, side, d_out, so, nbuf, it, rows_per_wave, C.byref(us)), "musica_k_reduce_timed_rot")
+                self._ok(self._lib.musica_k_reduce_timed_rot(self._h, d_in, side, side, d_out, so, nbuf, it, C.byref(us)), "musica_k_reduce_timed_rot")
             if copy_ceiling:
                 for it in (nbuf, iters):
                     self._ok(self._lib.musica_k_copy41_timed_rot(self._h, d_in, side, d_out, nbuf, it, C.byref(cus)), "musica_k_copy41_timed_rot")

@@ -23,7 +23,7 @@ def _declared_symbols():
 def test_library_is_built_and_loads():
     assert os.path.exists(mp.LIB_PATH), "run build() first: libmusica_hip.so missing"
     lib = mp.load_library()
-    assert lib.musica_abi_version() == 1
+    assert lib.musica_abi_version() == 2
 
 
 def test_exports_every_declared_symbol():
