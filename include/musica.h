@@ -103,6 +103,11 @@ typedef struct musica_stats {
                                         three-stream form: for contexts that run beside other contexts on one GPU (each then owns one
                                         stream = one hardware queue; 4 such contexts with alternating steps: +15 % throughput) */
 #define MUSICA_FLAG_NO_AUTOTUNE 0x8u /* skip the init-time launch-geometry autotune (rows per wavefront stay heuristic) */
+#define MUSICA_FLAG_REFERENCE_ORDER 0x20u /* the shaders' literal arithmetic order: img_smooth.comp:32-45, img_smooth_upsampled.comp:32-45
+                                        (with the * 4.0 per tap) and img_sdev.comp:17-30 accumulate their 25 taps m (x) outer,
+                                        n (y) inner, starting from 0. One thread per texel (as the shaders run), several times
+                                        slower than the default separable order; results are bit-identical to the oracle's
+                                        MUSICA_ORDER_REFERENCE. The default order is tolerance-close to this one. */
 
 /* Construction parameters: the reference hard-wires these as literals
  * (imageSize = 3072 in test/standalone/main.cpp:31; L = ceil(log2 N) in

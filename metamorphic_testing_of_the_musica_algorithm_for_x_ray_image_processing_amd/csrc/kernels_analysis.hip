@@ -230,6 +230,26 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __r
 }
 
 // histogram only (kernel-level parity tests feed a foreign sdev image): same scan, no stencil.
+// img_sdev.comp:10-35 literally: sum += pixel * pixel over m (x) outer, n (y) inner, out-of-image taps 0 (Q1), sqrt(sum / 25).
+__global__ void k_sdev_literal(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch, size_t plane) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= S || y >= S) return;
+    band += (size_t)blockIdx.z * plane;
+    sdev += (size_t)blockIdx.z * plane;
+    float sum = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 5; m++) {
+#pragma unroll
+        for (int n = 0; n < 5; n++) {
+            const int px = x + m - 2, py = y + n - 2;
+            const float p = (px >= 0 && py >= 0 && px < S && py < S) ? band[(size_t)py * pitch + px] : 0.0f;
+            sum = sum + p * p;   // :23
+        }
+    }
+    sdev[(size_t)y * pitch + x] = sqrtf(sum / 25.0f);   // :30
+}
+
 __global__ __launch_bounds__(kBlockThreads) void k_noise_hist_only(const float* __restrict__ sdev, int S, int pitch, size_t plane,
                                                                    uint32_t* __restrict__ hist, size_t hist_stride, int cov) {
     __shared__ uint32_t lh[MUSICA_NOISE_BINS];
@@ -559,6 +579,10 @@ void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const Leve
     const dim3 grid(strips, (segs + kWavesPerBlock - 1) / kWavesPerBlock, batch);
     if ((l.S & 7) == 0) hipLaunchKernelGGL((k_sdev_hist_pf<true, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave, xcd_swizzle_on());
     else hipLaunchKernelGGL((k_sdev_hist_pf<true, false>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave, xcd_swizzle_on());
+}
+
+void launch_sdev_literal(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, int batch) {
+    hipLaunchKernelGGL(k_sdev_literal, dim3((l.S + 31) / 32, (l.S + 7) / 8, batch), dim3(32, 8), 0, st, band, sdev, l.S, l.pitch, l.plane);
 }
 
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch) {

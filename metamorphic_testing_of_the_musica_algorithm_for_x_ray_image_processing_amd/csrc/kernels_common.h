@@ -70,6 +70,14 @@ __device__ __forceinline__ void bstore4(const Buf& b, uint32_t off, float4 v) {
     u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
     llvm_buffer_store_v4f32(u, b.r, (int)off, 0, 0);
 }
+// Non-temporal form (aux bit 1 = nt): for kernels that read several bytes per byte they write and do not read their output
+// again (the metric kernel, reduce + band). Measured per kernel, not a blanket rule: the 1:1 streams (sdev, gradation apply)
+// and the expand launches are 5 - 20 % slower with it (round 3).
+__device__ __forceinline__ void bstore4_nt(const Buf& b, uint32_t off, float4 v) {
+    v4f u;
+    u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
+    llvm_buffer_store_v4f32(u, b.r, (int)off, 0, 2);
+}
 
 // ---- which tile a workgroup works on ----
 // The hardware hands workgroups to the 8 XCDs round-robin by linear workgroup id, and every XCD has an L2 of its own: with the

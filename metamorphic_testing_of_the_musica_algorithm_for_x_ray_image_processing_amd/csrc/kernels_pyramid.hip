@@ -79,6 +79,10 @@ __device__ __forceinline__ void store8(const Buf& b, uint32_t off, const float d
     bstore4(b, off, make_float4(d[0], d[1], d[2], d[3]));
     bstore4(b, off + 16u, make_float4(d[4], d[5], d[6], d[7]));
 }
+__device__ __forceinline__ void store8_nt(const Buf& b, uint32_t off, const float d[8]) {
+    bstore4_nt(b, off, make_float4(d[0], d[1], d[2], d[3]));
+    bstore4_nt(b, off + 16u, make_float4(d[4], d[5], d[6], d[7]));
+}
 
 __device__ __forceinline__ void load_row(RowR& r, const Buf& b, uint32_t row_off, const LaneCfg& g) {
     load8(r.v, b, g.off + row_off);
@@ -302,13 +306,36 @@ __device__ __forceinline__ float ld0(const float* __restrict__ im, int pitch, in
     return (x >= 0 && y >= 0 && x < S && y < S) ? im[(size_t)y * pitch + x] : 0.0f;
 }
 
+// ---- the shaders' literal arithmetic order (MUSICA_FLAG_REFERENCE_ORDER) ---------------------------------------
+// img_smooth.comp:32-45 / img_smooth_upsampled.comp:32-45 accumulate the 25 taps m (x) outer, n (y) inner,
+// `pixel += weight[m] * weight[n] [* 4.0] * load`, starting from 0; img_sdev.comp:17-30 the 25 squares likewise.
+// The generic kernels take a wave-uniform `ref` argument and then evaluate exactly that sequence (the oracle's
+// MUSICA_ORDER_REFERENCE); speed is secondary here.
+__device__ __forceinline__ float w5(int i) { return i == 0 ? W0 : i == 1 ? W1 : i == 2 ? W2 : i == 3 ? W3 : W4; }
+
+__device__ __forceinline__ float smooth_literal(const float* __restrict__ in, int pitch, int S, int x, int y) {
+    const int hi = S - 1;
+    float pixel = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 5; m++) {
+        const int xm = mirror_idx(x + m - 2, hi);
+#pragma unroll
+        for (int n = 0; n < 5; n++) pixel = pixel + (w5(m) * w5(n)) * ld0(in, pitch, S, xm, mirror_idx(y + n - 2, hi));   // img_smooth.comp:43
+    }
+    return pixel;
+}
+
 __global__ void k_reduce_generic(const float* __restrict__ in, float* __restrict__ out, int S, int pitch,
-                                 size_t in_plane, int So, int opitch, size_t out_plane) {
+                                 size_t in_plane, int So, int opitch, size_t out_plane, int ref) {
     const int xo = blockIdx.x * blockDim.x + threadIdx.x;
     const int yo = blockIdx.y * blockDim.y + threadIdx.y;
     if (xo >= So || yo >= So) return;
     in += (size_t)blockIdx.z * in_plane;
     out += (size_t)blockIdx.z * out_plane;
+    if (ref) {   // img_downsample.comp:15 of the literally smoothed image
+        out[(size_t)yo * opitch + xo] = smooth_literal(in, pitch, S, 2 * xo, 2 * yo);
+        return;
+    }
     const int hi = S - 1;
     float v[5];
 #pragma unroll
@@ -528,8 +555,8 @@ __device__ __forceinline__ void band_pair(const CRow& a, const CRow& b, const CR
         be[j] = fe.v[j] - lowE[j];   // img_difference.comp:15
         bo[j] = fo.v[j] - lowO[j];
     }
-    store8(bb, g.off + off_e, be);
-    store8(bb, g.off + off_o, bo);
+    store8_nt(bb, g.off + off_e, be);   // non-temporal: the band image is next read by another launch (C5 level 0: 108 -> 90 us)
+    store8_nt(bb, g.off + off_o, bo);
 }
 
 // bit j: fe.v[j] <= 0.9, bit 8 + j: fo.v[j] <= 0.9 — the shader's own comparison on the normalized value (NaN: false)
@@ -620,7 +647,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __
         }
         coarse_row(c0, w0, w1, w2, w3, w4, g);
         if (k >= k0 && k < k1)  // wave-uniform
-            bstore4(db, g.coff + (uint32_t)k * crb, make_float4(c0.v[0], c0.v[1], c0.v[2], c0.v[3]));
+            bstore4_nt(db, g.coff + (uint32_t)k * crb, make_float4(c0.v[0], c0.v[1], c0.v[2], c0.v[3]));
         // coarse row k completes the neighbourhood of row k-1: band rows 2(k-1), 2(k-1)+1 are the two oldest rows of the window.
         // km1(0) = coarse_of_fine(-2) = 1 (reflect-101 on the fine grid, img_smooth_upsampled.comp:10-16): row k itself.
         const int kp = k - 1;
@@ -639,7 +666,21 @@ __global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __
 }
 
 // lowpass value at fine (x, y) for any S (generic form).
-__device__ __forceinline__ float lowpass_generic(const float* __restrict__ coarse, int cpitch, int Sc, int S, int x, int y) {
+__device__ __forceinline__ float lowpass_generic(const float* __restrict__ coarse, int cpitch, int Sc, int S, int x, int y, int ref) {
+    if (ref) {   // img_smooth_upsampled.comp:32-45 on the zero-inserted image of img_upsample.comp (odd texels: 0, Q2), literally
+        float pixel = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            const int j = coarse_of_fine(x + m - 2, S);
+#pragma unroll
+            for (int n = 0; n < 5; n++) {
+                const int k = coarse_of_fine(y + n - 2, S);
+                const float tap = (j >= 0 && k >= 0) ? ld0(coarse, cpitch, Sc, j, k) : 0.0f;
+                pixel = pixel + ((w5(m) * w5(n)) * 4.0f) * tap;   // :43
+            }
+        }
+        return pixel;
+    }
     float V[5];
 #pragma unroll
     for (int m = 0; m < 5; m++) {
@@ -662,26 +703,26 @@ __device__ __forceinline__ float lowpass_generic(const float* __restrict__ coars
 }
 
 __global__ void k_band_generic(const float* __restrict__ fine, const float* __restrict__ coarse, float* __restrict__ band,
-                               int S, int pitch, size_t plane, int Sc, int cpitch, size_t cplane) {
+                               int S, int pitch, size_t plane, int Sc, int cpitch, size_t cplane, int ref) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= S || y >= S) return;
     fine += (size_t)blockIdx.z * plane;
     band += (size_t)blockIdx.z * plane;
     coarse += (size_t)blockIdx.z * cplane;
-    const float low = lowpass_generic(coarse, cpitch, Sc, S, x, y);
+    const float low = lowpass_generic(coarse, cpitch, Sc, S, x, y, ref);
     band[(size_t)y * pitch + x] = fine[(size_t)y * pitch + x] - low;
 }
 
 // lowpass only (debugProcess' red_lowpass_i / exp_lowpass_i dumps, kernel-level tests)
 __global__ void k_lowpass_generic(const float* __restrict__ coarse, float* __restrict__ low, int S, int pitch, size_t plane,
-                                  int Sc, int cpitch, size_t cplane) {
+                                  int Sc, int cpitch, size_t cplane, int ref) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= S || y >= S) return;
     low += (size_t)blockIdx.z * plane;
     coarse += (size_t)blockIdx.z * cplane;
-    low[(size_t)y * pitch + x] = lowpass_generic(coarse, cpitch, Sc, S, x, y);
+    low[(size_t)y * pitch + x] = lowpass_generic(coarse, cpitch, Sc, S, x, y, ref);
 }
 
 // ======================================================================================
@@ -969,7 +1010,7 @@ __global__ void k_expand_generic(ExpandArgs a) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= a.S || y >= a.S) return;
-    const float low = lowpass_generic(a.prev + (size_t)img * a.cplane, a.cpitch, a.Sc, a.S, x, y);
+    const float low = lowpass_generic(a.prev + (size_t)img * a.cplane, a.cpitch, a.Sc, a.S, x, y, a.ref_order);
     a.recon[(size_t)img * a.plane + (size_t)y * a.pitch + x] = low + exp_band_at<GAIN, NR>(a, tab, img, x, y);
 }
 
@@ -1009,7 +1050,7 @@ static const dim3 kGenericBlock(32, 8, 1);
 static inline bool fast_ok(int S) { return S >= 8 && (S % 8) == 0; }
 
 // tag: launch site (see k_reduce_dma)
-void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, bool force_generic, int tag) {
+void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, bool force_generic, int tag, int ref) {
     if (fast_ok(li.S) && !force_generic) {
         const int strips = (li.S + kStripCols - 1) / kStripCols;
         const dim3 grid(strips, (lo.S + kDmaRows - 1) / kDmaRows, batch);
@@ -1020,7 +1061,7 @@ void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* 
         hipLaunchKernelGGL(kern, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, swz);
     } else {
         hipLaunchKernelGGL(k_reduce_generic, generic_grid(lo.S, batch), kGenericBlock, 0, st, in, out, li.S, li.pitch,
-                           li.plane, lo.S, lo.pitch, lo.plane);
+                           li.plane, lo.S, lo.pitch, lo.plane, ref);
     }
 }
 
@@ -1051,7 +1092,7 @@ void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, fl
 }
 
 void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc,
-                 int batch, int rows_per_wave, bool force_generic, int rows_per_trip) {
+                 int batch, int rows_per_wave, bool force_generic, int rows_per_trip, int ref) {
     if (fast_ok(lf.S) && !force_generic) {
         const dim3 grid = stream_grid(lf.S, lc.S, rows_per_wave, batch);
         if (rows_per_trip >= 2)
@@ -1060,13 +1101,13 @@ void launch_band(hipStream_t st, const float* fine, const float* coarse, float* 
             hipLaunchKernelGGL((k_band_fast<1, false>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, nullptr, 0);
     } else {
         hipLaunchKernelGGL(k_band_generic, generic_grid(lf.S, batch), kGenericBlock, 0, st, fine, coarse, band, lf.S, lf.pitch,
-                           lf.plane, lc.S, lc.pitch, lc.plane);
+                           lf.plane, lc.S, lc.pitch, lc.plane, ref);
     }
 }
 
-void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch) {
+void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch, int ref) {
     hipLaunchKernelGGL(k_lowpass_generic, generic_grid(lf.S, batch), kGenericBlock, 0, st, coarse, low, lf.S, lf.pitch, lf.plane,
-                       lc.S, lc.pitch, lc.plane);
+                       lc.S, lc.pitch, lc.plane, ref);
 }
 
 template <int GAIN, bool NR>

@@ -41,6 +41,7 @@ struct ExpandArgs {
     const uint16_t* le090;   // or: [batch][Sc][S / 8] bits of `normalized <= 0.9` written by launch_reduce_band_u16 (then raw / thr090 are not read)
     int swz;                 // XCD-aware tile mapping (kernels_common.h xcd_tile)
     const int* thr090;       // [batch]: largest raw value whose normalized value is <= 0.9 (k_curves_cnr)
+    int ref_order;           // generic kernels: the shaders' literal 25-tap order (MUSICA_FLAG_REFERENCE_ORDER)
 };
 
 struct GradArgs {
@@ -59,8 +60,9 @@ struct GradArgs {
 };
 
 // kernels_pyramid.hip
-void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, bool force_generic, int tag);
-void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave, bool force_generic, int rows_per_trip);
+// ref != 0 (generic kernels only): the shaders' literal 25-tap accumulation order (MUSICA_FLAG_REFERENCE_ORDER)
+void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, bool force_generic, int tag, int ref = 0);
+void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave, bool force_generic, int rows_per_trip, int ref = 0);
 void launch_reduce_u16(hipStream_t st, const uint16_t* px, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave,
                        const uint32_t* minmax, int min_chain_exact);
 void launch_reduce_band_u16(hipStream_t st, const uint16_t* px, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
@@ -68,7 +70,7 @@ void launch_reduce_band_u16(hipStream_t st, const uint16_t* px, float* down, flo
 void launch_reduce_band(hipStream_t st, const float* fine, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave);
 void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                      int rows_per_wave, int rows_per_trip, const uint32_t* minmax, int min_chain_exact);
-void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch);
+void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch, int ref = 0);
 void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic, int rows_per_trip);
 void launch_exp_band(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch);
 // kernels_analysis.hip
@@ -78,6 +80,8 @@ void launch_normalize(hipStream_t st, const uint16_t* px, float* out, const Leve
 void launch_sqrt(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, int batch);
 void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch, int rows_per_wave);
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch);
+// img_sdev.comp:10-35 with the 25 squares accumulated in the shader's order (one thread per texel; MUSICA_FLAG_REFERENCE_ORDER)
+void launch_sdev_literal(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, int batch);
 void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves, const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const uint32_t* minmax, int min_chain_exact, int* thr090, int lev0 = 0, int nlev = 0);
 void launch_curves_cnr(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves,
                        const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const float* sdev, float* cnr,

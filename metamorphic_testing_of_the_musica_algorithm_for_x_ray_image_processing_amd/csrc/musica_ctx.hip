@@ -58,6 +58,7 @@ struct musica_ctx {
     musica_params p;
     int N, L, B;
     bool generic;
+    int ref_order;           // MUSICA_FLAG_REFERENCE_ORDER: generic kernels in the shaders' literal 25-tap accumulation order
     bool tuning;  // inside autotune(): launches are tagged so profilers keep them apart
     LevelDesc lv[MUSICA_MAX_LEVELS + 1];
     int min_chain_exact;
@@ -377,7 +378,8 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->p = *params;
     c->N = (int)N; c->L = (int)L; c->B = params->batch ? (int)params->batch : 1;
     c->p.levels = L; c->p.batch = (uint32_t)c->B;
-    c->generic = (params->flags & MUSICA_FLAG_GENERIC_KERNELS) != 0;
+    c->ref_order = (params->flags & MUSICA_FLAG_REFERENCE_ORDER) ? 1 : 0;
+    c->generic = (params->flags & MUSICA_FLAG_GENERIC_KERNELS) != 0 || c->ref_order;   // the literal order lives in the one-thread-per-texel kernels
     c->tuning = false;
     c->stream = nullptr; c->side = nullptr; c->side1 = nullptr; c->ev_s1 = nullptr; c->ev_s2 = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr; c->profiling = 0; c->spans_used = 0; c->cur_input = nullptr;
     c->ev_gfork = nullptr; c->ev_gdone = nullptr; c->first_image = 0;
@@ -428,7 +430,7 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->graph_exec[0] = c->graph_exec[1] = nullptr;
     c->graph_input[0] = c->graph_input[1] = nullptr;
     c->graph_next = 0;
-    c->fuse_u16 = env_int("MUSICA_U16", 1) != 0 && (N % 8) == 0 && !(params->flags & MUSICA_FLAG_GENERIC_KERNELS);
+    c->fuse_u16 = env_int("MUSICA_U16", 1) != 0 && (N % 8) == 0 && !c->generic;
     c->norm_valid = false;
     c->fuse_rb = c->generic ? 0 : env_int("MUSICA_FUSE_RB", 2);
     if (!c->fuse_u16 && c->fuse_rb == 1) c->fuse_rb = 0;
@@ -585,7 +587,7 @@ static void run_reduce_level(musica_ctx* c, int i, int rows) {
         launch_reduce_u16(c->cur, c->cur_input, c->lv[0], c->d_down[0], c->lv[1], c->B, rows, c->d_minmax, c->min_chain_exact);
         return;
     }
-    launch_reduce(c->cur, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, c->generic, i == 0 ? 0 : 1);   // one fixed tile shape: `rows` only steers the uint16 form
+    launch_reduce(c->cur, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, c->generic, i == 0 ? 0 : 1, c->ref_order);   // one fixed tile shape: `rows` only steers the uint16 form
 }
 // reduce + band of a level in one launch
 static bool rb_level(const musica_ctx* c, int i) {
@@ -603,7 +605,7 @@ static void run_band_level(musica_ctx* c, int i, int rows) {
         launch_band_u16(c->cur, c->cur_input, c->d_down[0], c->d_band[0], c->lv[0], c->lv[1], c->B, rows, c->band_trip, c->d_minmax, c->min_chain_exact);
         return;
     }
-    launch_band(c->cur, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, rows, c->generic, c->band_trip);
+    launch_band(c->cur, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, rows, c->generic, c->band_trip, c->ref_order);
 }
 // reduce and band of level i, as one launch where that form applies
 static void run_reduce_and_band(musica_ctx* c, int i) {
@@ -612,6 +614,11 @@ static void run_reduce_and_band(musica_ctx* c, int i) {
     { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
 }
 static void run_sdev_level(musica_ctx* c, int i, int rows) {
+    if (c->ref_order) {   // img_sdev.comp literally, then noise_hist.comp on the stored image
+        launch_sdev_literal(c->cur, c->d_band[i], c->d_sdev[i], c->lv[i], c->B);
+        launch_noise_hist_only(c->cur, c->d_sdev[i], c->lv[i], c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS, (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov, c->B);
+        return;
+    }
     launch_sdev_hist(c->cur, c->d_band[i], c->d_sdev[i], c->lv[i], c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS,
                      (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov, c->B, rows);
 }
@@ -661,6 +668,7 @@ static ExpandArgs expand_args(musica_ctx* c, int lvl, float* dst) {
     a.rows_per_wave = c->rows_expand[lvl];
     a.raw = nullptr; a.ghist = nullptr; a.gzero = nullptr; a.thr090 = nullptr; a.le090 = nullptr;
     a.swz = xcd_swizzle_on();
+    a.ref_order = c->ref_order;
     return a;
 }
 static int gain_mode(int lvl) { return lvl > MUSICA_CNR_LEVEL ? GAIN_CONST : (lvl == MUSICA_CNR_LEVEL ? GAIN_RANGE : GAIN_CURVE); }
@@ -1139,7 +1147,7 @@ static int resolve_image(musica_ctx* c, uint32_t idx, musica_image_kind kind, ui
             launch_sqrt(c->stream, c->cur_input, c->d_scratch, l0, c->B);
             *plane = c->d_scratch + idx * l0.plane; *desc = &c->lv[0]; return 1;
         case MUSICA_IMG_LOWPASS:  // lowpassImageStates[level] = smooth_upsampled(upsample(downsampled[level]))
-            launch_lowpass(c->stream, c->d_down[level], c->d_scratch, c->lv[level], c->lv[level + 1], c->B);
+            launch_lowpass(c->stream, c->d_down[level], c->d_scratch, c->lv[level], c->lv[level + 1], c->B, c->ref_order);
             *plane = c->d_scratch + idx * c->lv[level].plane; *desc = &c->lv[level]; return 1;
         case MUSICA_IMG_EXP_BANDPASS: case MUSICA_IMG_CONTRAST_BAND: {
             const ExpandArgs a = expand_args(c, (int)level, c->d_scratch);

@@ -1,4 +1,4 @@
-// musica-standalone <raw_path> <out_path> [--size N] [--levels L] [--device D] [--debug-dir DIR]
+// musica-standalone <raw_path> <out_path> [--size N] [--levels L] [--device D] [--debug-dir DIR] [--reference-order] [--clahe]
 //
 // Drop-in for the reference's `maverick-standalone.exe <raw_path>.raw <out_path>.bmp`
 // (test/standalone/README.md:3, test/standalone/main.cpp:30-87), which is what the metamorphic
@@ -8,8 +8,11 @@
 //   * init(3072) -> execute -> saveOutImage(out), exit 0; any failure prints
 //     "MAIN ERROR: <msg>" to stderr and exits 1 (main.cpp:7-11).
 // Extensions that keep the two-argument form compatible: --size / --levels (also MUSICA_SIZE /
-// MUSICA_LEVELS in the environment), --device, and --debug-dir (the debugProcess() dumps that the
-// reference writes in non-NDEBUG builds, main.cpp:81-83).
+// MUSICA_LEVELS in the environment), --device, --debug-dir (the debugProcess() dumps that the
+// reference writes in non-NDEBUG builds, main.cpp:81-83), --reference-order (MUSICA_FLAG_REFERENCE_ORDER: the shaders'
+// literal 25-tap accumulation order) and --clahe (#define ENABLE_CLAHE of include/vk_processing.h:13).
+// One process = one execute: the context is created without the launch-geometry autotune and without graph capture
+// (both pay off only over many executes of one context; the reference's harness spawns a process per image).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -31,6 +34,7 @@ int main(int argc, char* argv[]) {
     uint32_t levels = 0;        // ceil(log2 N), src/vk_processing.cpp:1989
     int device = 0;
     const char* debugDir = nullptr;
+    uint32_t flags = MUSICA_FLAG_NO_AUTOTUNE | MUSICA_FLAG_NO_GRAPH;
     if (const char* e = getenv("MUSICA_SIZE")) imageSize = (uint32_t)atoi(e);
     if (const char* e = getenv("MUSICA_LEVELS")) levels = (uint32_t)atoi(e);
 
@@ -42,6 +46,8 @@ int main(int argc, char* argv[]) {
         else if (!strcmp(argv[i], "--levels") && i + 1 < argc) levels = (uint32_t)atoi(argv[++i]);
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--debug-dir") && i + 1 < argc) debugDir = argv[++i];
+        else if (!strcmp(argv[i], "--reference-order")) flags |= MUSICA_FLAG_REFERENCE_ORDER;
+        else if (!strcmp(argv[i], "--clahe")) flags |= MUSICA_FLAG_CLAHE;
         else pos.push_back(argv[i]);
     }
     ASSERT_MSG(pos.size() == 2, "wrong number of arguments");  // main.cpp:37
@@ -57,6 +63,7 @@ int main(int argc, char* argv[]) {
     p.levels = levels;
     p.batch = 1;
     p.device = device;
+    p.flags = flags;
     musica_ctx* ctx = musica_create(&p);
     ASSERT_MSG(ctx != nullptr, "failed to initialize vk processing");  // main.cpp:51 (message kept)
 
