@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — full-pipeline MUSICA throughput on N MI355X GPUs + roofline of the metric kernel.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C4|C2|C3|C5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C4|C2|C3|C5|REF]
 
 One "step" = one pass of the whole hot path (minmax -> pyramid reduce -> analysis -> contrast /
 noise-reduction + expand -> gradation) over one batch of synthetic raw images already resident in
@@ -52,6 +52,8 @@ WORKLOADS = {
     "C2": (2048, 6, 1, 16, 0, "C2: 1 x 2048x2048 u16, 6-level pyramid (BASELINE configs[1])"),
     "C3": (4096, 8, 1, 16, 1, "C3: 1 x 4096x4096 u16, 8-level pyramid + CLAHE gradation (BASELINE configs[2])"),
     "C5": (8192, 10, 1, 12, 0, "C5: 1 x 8192x8192 12-bit, 10-level pyramid, noise reduction on (BASELINE configs[4])"),
+    # the reference's own call: one 3072 x 3072 image (test/standalone/main.cpp:31), L = ceil(log2 N) = 12 (src/vk_processing.cpp:1989)
+    "REF": (3072, 12, 1, 16, 0, "REF: 1 x 3072x3072 u16, 12-level pyramid: the configuration maverick-standalone runs (test/standalone/main.cpp:31)"),
 }
 COLD_BUFFERS = 8          # 8 x (64 MB in + 16 MB out) = 640 MB rotating footprint for the HBM measurement
 COLD_ITERS = 64
@@ -112,6 +114,7 @@ def parse_args():
     ap.add_argument("--no-single-image", action="store_true", help="skip the one-image-per-execute measurement (keeps a kernel trace of the run pure)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel event passes after the timed region")
     ap.add_argument("--no-standalone", action="store_true", help="skip the stand-alone 4096^2 metric-kernel measurements (roofline becomes the in-pipeline launch)")
+    ap.add_argument("--no-cli", action="store_true", help="skip the drop-in measurement (musica-standalone <raw> <bmp> in fresh processes at 3072^2 / L12)")
     return ap.parse_args()
 
 
@@ -173,6 +176,8 @@ def main():
 
     if not torch.cuda.is_available() or mp.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the MUSICA path has no CPU fallback")
+    if torch.cuda.device_count() < local_rank + 1:
+        raise SystemExit("rank %d wants cuda:%d but only %d device(s) are visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:
@@ -377,6 +382,12 @@ def main():
                         "copy_ceiling": {"kernel": "k_copy41: plain streaming kernel, same traffic shape (read S^2 f32, write (S/2)^2 f32), same rotation",
                                          "achieved": gb(copy_us), "unit": "GB/s", "mean_us": round(copy_us, 2),
                                          "metric_kernel_vs_ceiling": round(copy_us / cold_us, 4)}}
+            # the same kernel at 8192 x 8192 (3 plane pairs = 1 GB rotating footprint), reported beside the 4096^2 figure
+            b8192 = 5 * 8192 * 8192
+            cold8_us, copy8_us = proc.k_reduce_cold(8192, nbuf=3, iters=24)
+            roofline["at_8192"] = {"achieved": round(b8192 / (cold8_us * 1e-6) / 1e9, 1), "unit": "GB/s", "frac": round(b8192 / (cold8_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "mean_us": round(cold8_us, 2), "algorithmic_bytes_per_launch": b8192,
+                                   "copy_ceiling_us": round(copy8_us, 2), "measured": "24 back-to-back launches rotating over 3 distinct 8192x8192 plane pairs (1 GB)"}
             warm = {"kernel": "the same kernel, 200 back-to-back launches on ONE 4096x4096 input (80 MB: cache-resident in the 256 MiB Infinity Cache, not an HBM number)",
                     "bound": "infinity-cache", "achieved": gb(warm_us), "unit": "GB/s", "frac_of_hbm_peak": round(gb(warm_us) / HBM_PEAK_GBS, 4),
                     "mean_us": round(warm_us, 2), "algorithmic_bytes_per_launch": b4096}
@@ -418,6 +429,59 @@ def main():
                 single = {"workload": "1 x %dx%d per execute, %d-level pyramid (BASELINE configs[1] shape)" % (n, n, levels),
                           "value": round(n * n / 1e6 / ts, 1), "unit": "MP/s", "ms_per_image": round(ts * 1e3, 4)}
                 p1.cleanup()
+        # The reference's own call shape and the drop-in itself: one 3072 x 3072 image, L = 12 (test/standalone/main.cpp:31,
+        # src/vk_processing.cpp:1989). (a) one context, one image per execute, resident input; (b) `musica-standalone <raw> <bmp>` as
+        # test/metamorphic_test/script.py:200-214 spawns it: wall time of fresh processes (median of 5) and the CLI's own timing line.
+        ref = None
+        cli = None
+        if world == 1 and not args.no_cli:
+            import re
+            import tempfile
+            rn = 3072
+            rpx = phantom(rn, 31)
+            pr = mp.MusicaProcessing(device=local_rank)
+            if pr.init(rn, levels=0, batch=1, flags=0):
+                pr.upload(rpx[None])
+                for _ in range(3):
+                    pr.execute_device()
+                pr.sync()
+                tr0 = time.perf_counter()
+                for _ in range(args.steps):
+                    pr.execute_device()
+                pr.sync()
+                tr_dev = (time.perf_counter() - tr0) / args.steps
+                tr0 = time.perf_counter()
+                for _ in range(3):
+                    pr.execute(rpx)
+                tr_host = (time.perf_counter() - tr0) / 3
+                ref = {"workload": "1 x 3072x3072 per execute, 12-level pyramid (the reference's configuration), one context",
+                       "ms_per_image_resident_input": round(tr_dev * 1e3, 4), "MPps_resident_input": round(rn * rn / 1e6 / tr_dev, 1),
+                       "ms_per_image_host_input_synchronous": round(tr_host * 1e3, 4)}
+                pr.cleanup()
+            with tempfile.TemporaryDirectory() as td:
+                from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.phantom import write_raw
+                raw, out = os.path.join(td, "image.raw"), os.path.join(td, "out.bmp")
+                write_raw(raw, rpx)
+                walls, lines = [], []
+                for _ in range(5):
+                    tc0 = time.perf_counter()
+                    r = subprocess.run([mp.CLI_PATH, raw, out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                    walls.append((time.perf_counter() - tc0) * 1e3)
+                    if r.returncode != 0:
+                        raise SystemExit("musica-standalone failed: " + r.stderr)
+                    m = re.search(r"init: ([0-9.]+) .*exec: ([0-9.]+) .*save: ([0-9.]+) .*tot: ([0-9.]+)", r.stdout)
+                    m2 = re.search(r"hip start-up: ([0-9.]+) .*create: ([0-9.]+) .*read: ([0-9.]+)", r.stdout)
+                    m3 = re.search(r"cleanup: ([0-9.]+)", r.stdout)
+                    if m:
+                        lines.append([float(v) for v in m.groups()] + ([float(v) for v in m2.groups()] if m2 else [0.0, 0.0, 0.0]) + [float(m3.group(1)) if m3 else 0.0])
+                order = sorted(range(len(walls)), key=lambda i: walls[i])
+                mid = order[len(order) // 2]
+                cli = {"command": "musica-standalone image.raw out.bmp (3072x3072, L = 12, no flags), 5 fresh processes",
+                       "wall_ms_median": round(walls[mid], 1), "wall_ms_all": [round(w, 1) for w in walls],
+                       "own_line_ms_of_the_median_run": dict(zip(["init", "exec", "save", "tot", "hip_startup", "create", "read", "cleanup"], lines[mid])) if len(lines) == len(walls) else None,
+                       "note": "init = hip_startup (first HIP call) + create (device allocation, streams) + read (raw file); exec = H2D + pipeline incl. the first-launch "
+                               "code-object loads; save = device crop + quantise, 1 B/px D2H into pinned memory, 28 MB BMP write; cleanup = musica_destroy; "
+                               "wall - tot - cleanup = process start (dynamic loading of the HIP runtime) and exit. No autotune, no graph capture in one-shot use."}
         # CPU baseline: the oracle (a port — the reference has no CPU path), all host cores, bounded sample
         cpu = None
         if args.cpu_seconds > 0 and world == 1:
@@ -462,7 +526,8 @@ def main():
                        "queue_calibration_ms": queue_calibration,
                        "input": "seeded phantoms, %d-bit" % bits, "dispatch": "eager launches" if (kernel_events or os.environ.get("MUSICA_GRAPH", "1") == "0") else "hipGraph replay",
                        "kernel_events_in_timed_region": kernel_events, "sharding": "image k -> rank k mod N, no data-path collective",
-                       "stats_gathered": int(st.shape[0]), "ranks_joined": world},
+                       "stats_gathered": int(st.shape[0]), "ranks_joined": world,
+                       "collective": ("%s all_gather_into_tensor of %d stats rows per rank" % ("RCCL (torch backend nccl)" if args.backend == "nccl" else "gloo", batch)) if distributed else "none (one rank)"},
             "parity": "timed path = default (separable) order: bit-identical to the build's CPU oracle in that order; with MUSICA_FLAG_REFERENCE_ORDER the GPU runs the "
                       "shaders' literal 25-tap order, bit-identical to the oracle's literal restatement on every BASELINE config and 3072/L12 (tests/test_gpu_reference_order.py). "
                       "Default vs literal order, measured at full size on every config (profiles/r03_literal_order_*.json): stencil outputs within 6e-7 / 1e-6, every "
@@ -476,6 +541,8 @@ def main():
             "e2e_host_overlapped": {"value": round(e2e_stream, 1), "unit": "MP/s", "what": "musica_execute_stream over %d batches in pinned host memory: H2D of batch j+1 under the kernels of batch j (PCIe-inclusive; never `value`)" % reps,
                                     "pcie_bound_MPps": round(63e9 / 2 / 1e6, 1), "fraction_of_device_rate": round(e2e_stream / (mpix / elapsed), 3)},
             "single_image": single,
+            "reference_3072_L12": ref,
+            "cli": cli,
         }
     if depth > 1:
         proc.cleanup()

@@ -188,7 +188,11 @@ int musica_execute(musica_ctx* ctx, const uint16_t* pixels);
 
 /* Same pipeline with the input already resident in HBM: `d_pixels` is a device
  * pointer to batch * N * N uint16 (dense). Enqueues on the ctx stream and
- * returns without waiting; pair with musica_sync(). */
+ * returns without waiting; pair with musica_sync(). The dispatch script is
+ * captured into a hipGraph once per distinct `d_pixels` and replayed afterwards;
+ * a context keeps the graphs of the 4 most recently used pointers (rotating more
+ * than 4 buffers through one context recaptures — a host-side stall of about a
+ * millisecond plus a stream drain — every time a pointer comes back). */
 int musica_execute_device(musica_ctx* ctx, const uint16_t* d_pixels);
 
 /* Uploads host pixels into the ctx-owned resident input buffer and returns its
@@ -283,11 +287,6 @@ int musica_pipeline_prime(musica_pipeline* p, uint32_t calibration_steps);
 uint32_t musica_pipeline_calibration(const musica_pipeline* p, float* window_ms /* [MUSICA_PIPELINE_QUEUES] or NULL */);
 /* Enqueue one step on the next context: d_pixels (device memory, 16-byte aligned) or, when NULL, that context's own input. */
 int musica_pipeline_step(musica_pipeline* p, const uint16_t* d_pixels);
-/* The same from host memory (batch x N x N uint16): the host-to-device copy is enqueued on the next context's stream in front of
- * its step, i.e. it runs under the kernels of the other contexts (what replaces VulkanState::loadDataToImage's staging upload
- * with three queue-idle waits, src/vk_state.cpp:313-342). `pixels` must stay valid until that context is synchronised or has
- * been handed a later step; pinned memory (musica_host_alloc) moves at the PCIe rate. */
-int musica_pipeline_step_host(musica_pipeline* p, const uint16_t* pixels);
 /* The context the most recent step was enqueued on. */
 musica_ctx* musica_pipeline_last(musica_pipeline* p);
 int musica_pipeline_sync(musica_pipeline* p);

@@ -553,6 +553,23 @@ void launch_grad_curve(hipStream_t st, uint32_t* hist, musica_hist_max_point* gm
     hipLaunchKernelGGL(k_grad_curve, dim3(batch), dim3(1024), 0, st, hist, gmax, curves, hist_b, gzero);
 }
 
+// saveOutImage (src/vk_processing.cpp:2624-2634): crop `margin` texels on every side and quantise, (uint8_t)(255.0f * (v - 0) / (1 - 0)),
+// on the device, so that the read-back is 1 byte per output pixel instead of 4 bytes per input pixel. The C cast is undefined
+// outside [0, 256): restated as the x86 lowering the reference's build gets (cvttss2si to int32, low byte kept; NaN and
+// values outside int32 give 0x80000000 -> 0), the same statement as the oracle's and dump_image's.
+__global__ __launch_bounds__(256) void k_out_pixels(const float* __restrict__ graded, int pitch, int margin, int nw, uint8_t* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= nw) return;
+    const float maxValue = 1.0f, minValue = 0.0f;
+    const float q = 255.0f * (graded[(size_t)(y + margin) * pitch + x + margin] - minValue) / (maxValue - minValue);
+    out[(size_t)y * nw + x] = (q == q && q > -2147483648.0f && q < 2147483648.0f) ? (uint8_t)(int32_t)q : (uint8_t)0;
+}
+void launch_out_pixels(hipStream_t st, const float* graded, const LevelDesc& l0, int margin, uint8_t* out) {
+    const int nw = l0.S - 2 * margin;
+    hipLaunchKernelGGL(k_out_pixels, dim3((nw + 255) / 256, nw), dim3(256), 0, st, graded, l0.pitch, margin, nw, out);
+}
+
 void launch_grad_apply(hipStream_t st, const float* in, float* out, const LevelDesc& l0, const DevCurve* curves, int batch) {
     // two 16-byte groups per thread and trip; ~16384 workgroups per launch is where a plain 1:1 stream peaks on this part
     // (devtools/stream11.hip: 46 us for 2 x 134 MB; 2048 workgroups 52 us, 65536 51 us)

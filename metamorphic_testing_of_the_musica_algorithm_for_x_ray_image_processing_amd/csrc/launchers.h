@@ -104,6 +104,8 @@ void launch_relevant(hipStream_t st, const float* normalized, const float* cnr, 
                      int cnrScale, int batch, const uint16_t* raw = nullptr, const int* thr090 = nullptr);
 void launch_grad_curve(hipStream_t st, uint32_t* hist, musica_hist_max_point* gmax, DevCurve* curves, int batch, const uint32_t* hist_b = nullptr, const uint32_t* gzero = nullptr);
 void launch_grad_apply(hipStream_t st, const float* in, float* out, const LevelDesc& l0, const DevCurve* curves, int batch);
+// crop + quantise of saveOutImage for ONE image plane: out = (S - 2 margin)^2 bytes, dense
+void launch_out_pixels(hipStream_t st, const float* graded, const LevelDesc& l0, int margin, uint8_t* out);
 // kernels_bench.hip (measurement aid)
 void launch_copy41(hipStream_t st, const float* in, float* out, int side);
 // kernels_clahe.hip

@@ -54,6 +54,9 @@ struct ProfSpan {
     hipEvent_t a, b;
 };
 
+// Captured graphs kept per context, one per distinct input pointer (include/musica.h, musica_execute_device).
+constexpr int kGraphSlots = 4;
+
 struct musica_ctx {
     musica_params p;
     int N, L, B;
@@ -75,9 +78,10 @@ struct musica_ctx {
     // hipGraph replay of the two-stream dispatch (captured once per input pointer; MUSICA_FLAG_NO_GRAPH /
     // MUSICA_GRAPH=0 / per-kernel profiling fall back to eager launches)
     bool use_graph;
-    hipGraphExec_t graph_exec[2];      // one captured graph per input pointer, the two most recently used (the streaming
-    const uint16_t* graph_input[2];    // path alternates between two device input buffers)
-    int graph_next;                    // slot the next capture overwrites
+    hipGraphExec_t graph_exec[kGraphSlots];      // one captured graph per input pointer, the kGraphSlots most recently used (the streaming
+    const uint16_t* graph_input[kGraphSlots];    // path alternates between two device input buffers; callers may rotate a few of their own)
+    uint64_t graph_used[kGraphSlots];            // launch counter at the slot's last use (least recently used slot is recaptured)
+    uint64_t graph_clock;
     int dag;                 // 0: one in-order stream; 1: three streams (levels 0-1 | coarse chain | sdev 2)
     // device state
     uint16_t* d_input;
@@ -116,6 +120,8 @@ struct musica_ctx {
     uint32_t* d_clahe_hist;
     musica_point* d_clahe_pts;
     float* d_clahe_graded;
+    uint8_t* d_out8;           // saveOutImage's cropped 8-bit pixels of one image (device) and their pinned host copy, allocated on first use
+    uint8_t* h_out8;
     // host parameters (src/vk_processing.cpp:259-297, 321-325)
     musica_contrast_params h_cparams[MUSICA_MAX_LEVELS];
     musica_nr_params h_nr[3];
@@ -228,7 +234,8 @@ static musica_ctx* make_view(const musica_ctx* c, int i0, int nb) {
     v->spans_used = 0;
     v->views.clear();
     v->stream = nullptr; v->side = nullptr; v->side1 = nullptr; v->ev_s1 = nullptr; v->ev_s2 = nullptr; v->ev_fork = nullptr; v->ev_join = nullptr; v->ev_gfork = nullptr; v->ev_gdone = nullptr;
-    v->graph_exec[0] = v->graph_exec[1] = nullptr; v->graph_input[0] = v->graph_input[1] = nullptr; v->graph_next = 0;   // every group captures and replays its own graphs
+    for (int k = 0; k < kGraphSlots; k++) { v->graph_exec[k] = nullptr; v->graph_input[k] = nullptr; v->graph_used[k] = 0; }   // every group captures and replays its own graphs
+    v->graph_clock = 0;
     v->first_image = i0;
     v->B = nb;
     v->p.batch = (uint32_t)nb;
@@ -319,7 +326,7 @@ void musica_destroy(musica_ctx* c) {
         if (v->ev_fork) hipEventDestroy(v->ev_fork);
         if (v->ev_join) hipEventDestroy(v->ev_join);
         if (v->ev_gdone) hipEventDestroy(v->ev_gdone);
-        for (int k = 0; k < 2; k++) if (v->graph_exec[k]) hipGraphExecDestroy(v->graph_exec[k]);
+        for (int k = 0; k < kGraphSlots; k++) if (v->graph_exec[k]) hipGraphExecDestroy(v->graph_exec[k]);
         delete v;
     }
     if (c->ev_gfork) hipEventDestroy(c->ev_gfork);
@@ -330,7 +337,8 @@ void musica_destroy(musica_ctx* c) {
     }
     for (auto& s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (void* p : c->allocations) hipFree(p);
-    for (int k = 0; k < 2; k++) if (c->graph_exec[k]) hipGraphExecDestroy(c->graph_exec[k]);
+    if (c->h_out8) hipHostFree(c->h_out8);
+    for (int k = 0; k < kGraphSlots; k++) if (c->graph_exec[k]) hipGraphExecDestroy(c->graph_exec[k]);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c->side1) { hipStreamSynchronize(c->side1); hipStreamDestroy(c->side1); }
     if (c->ev_s1) hipEventDestroy(c->ev_s1);
@@ -383,6 +391,7 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->tuning = false;
     c->stream = nullptr; c->side = nullptr; c->side1 = nullptr; c->ev_s1 = nullptr; c->ev_s2 = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr; c->profiling = 0; c->spans_used = 0; c->cur_input = nullptr;
     c->ev_gfork = nullptr; c->ev_gdone = nullptr; c->first_image = 0;
+    c->d_out8 = nullptr; c->h_out8 = nullptr;
     c->d_input2 = nullptr; c->copy_stream = nullptr; c->ev_copied[0] = c->ev_copied[1] = c->ev_consumed[0] = c->ev_consumed[1] = nullptr;
     memset(c->prof_total_us, 0, sizeof(c->prof_total_us));
     memset(c->prof_count, 0, sizeof(c->prof_count));
@@ -427,9 +436,8 @@ static musica_ctx* create_impl(const musica_params* params) {
         ok = ok && hipEventCreateWithFlags(&c->ev_s1, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->ev_s2, hipEventDisableTiming) == hipSuccess;
     }
-    c->graph_exec[0] = c->graph_exec[1] = nullptr;
-    c->graph_input[0] = c->graph_input[1] = nullptr;
-    c->graph_next = 0;
+    for (int k = 0; k < kGraphSlots; k++) { c->graph_exec[k] = nullptr; c->graph_input[k] = nullptr; c->graph_used[k] = 0; }
+    c->graph_clock = 0;
     c->fuse_u16 = env_int("MUSICA_U16", 1) != 0 && (N % 8) == 0 && !c->generic;
     c->norm_valid = false;
     c->fuse_rb = c->generic ? 0 : env_int("MUSICA_FUSE_RB", 2);
@@ -819,18 +827,28 @@ static void enqueue_script(musica_ctx* c) {
 
 // Captures enqueue_dag() (both streams: the side stream joins the capture through ev_fork and rejoins
 // through ev_join) into an executable graph for the current input pointer.
-static bool capture_graph(musica_ctx* c) {
-    const int k = c->graph_next;
-    if (c->graph_exec[k]) { hipGraphExecDestroy(c->graph_exec[k]); c->graph_exec[k] = nullptr; c->graph_input[k] = nullptr; }
+static int capture_graph(musica_ctx* c) {
+    int k = 0;   // an empty slot, else the least recently used one
+    for (int j = 0; j < kGraphSlots; j++) {
+        if (!c->graph_exec[j]) { k = j; break; }
+        if (c->graph_used[j] < c->graph_used[k]) k = j;
+    }
+    if (c->graph_exec[k]) {
+        // its last launch may still be running (musica_execute_device / musica_pipeline_step never wait): drain the stream before
+        // the executable graph goes away. Only callers that rotate more than kGraphSlots input pointers ever get here.
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+        hipGraphExecDestroy(c->graph_exec[k]);
+        c->graph_exec[k] = nullptr; c->graph_input[k] = nullptr;
+    }
     hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return -1;
     enqueue_script(c);
-    if (hipStreamEndCapture(c->stream, &graph) != hipSuccess || !graph) { (void)hipGetLastError(); return false; }
+    if (hipStreamEndCapture(c->stream, &graph) != hipSuccess || !graph) { (void)hipGetLastError(); return -1; }
     const hipError_t e = hipGraphInstantiate(&c->graph_exec[k], graph, nullptr, nullptr, 0);
     hipGraphDestroy(graph);
-    if (e != hipSuccess) { c->graph_exec[k] = nullptr; (void)hipGetLastError(); return false; }
+    if (e != hipSuccess) { c->graph_exec[k] = nullptr; (void)hipGetLastError(); return -1; }
     c->graph_input[k] = c->cur_input;
-    return true;
+    return k;
 }
 
 static int enqueue_all(musica_ctx* c);
@@ -862,13 +880,15 @@ static int enqueue_groups(musica_ctx* c) {
 static int enqueue_all(musica_ctx* c) {
     if (!c->views.empty() && !c->tuning) return enqueue_groups(c);
     if (!c->tuning && c->use_graph && c->profiling == 0) {
-        int k = (c->graph_exec[0] && c->graph_input[0] == c->cur_input) ? 0 : (c->graph_exec[1] && c->graph_input[1] == c->cur_input) ? 1 : -1;
+        int k = -1;
+        for (int j = 0; j < kGraphSlots; j++)
+            if (c->graph_exec[j] && c->graph_input[j] == c->cur_input) { k = j; break; }
         if (k < 0) {
-            if (!capture_graph(c)) c->use_graph = false;   // e.g. a runtime without capture support: stay eager
-            else k = c->graph_next;
+            k = capture_graph(c);
+            if (k < 0) c->use_graph = false;   // e.g. a runtime without capture support: stay eager
         }
         if (k >= 0) {
-            c->graph_next = k ^ 1;                         // the other slot is now the least recently used
+            c->graph_used[k] = ++c->graph_clock;
             c->norm_valid = (c->d_clahe_hist != nullptr && !c->clahe_raw) || !c->fuse_u16;
             if (hipGraphLaunch(c->graph_exec[k], c->stream) != hipSuccess) return fail("hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError()));
             return 1;
@@ -1031,11 +1051,16 @@ int musica_execute_stream(musica_ctx* c, const uint16_t* const* pixels, uint32_t
             HIP_OK(hipEventCreateWithFlags(&c->ev_consumed[k], hipEventDisableTiming));
         }
     }
+    if (count == 0) return 1;
     musica_stats* d_rows = nullptr;
     musica_stats* h_rows = nullptr;
+    struct RowsGuard {   // the two scratch buffers go away on every exit path
+        musica_stats*& d; musica_stats*& h;
+        ~RowsGuard() { if (d) hipFree(d); if (h) hipHostFree(h); }
+    } rows_guard{d_rows, h_rows};
     if (stats) {
         HIP_OK(hipMalloc(&d_rows, (size_t)count * c->B * sizeof(musica_stats)));
-        if (hipHostMalloc(&h_rows, (size_t)count * c->B * sizeof(musica_stats), hipHostMallocDefault) != hipSuccess) { hipFree(d_rows); return fail("musica_execute_stream: pinned allocation failed"); }
+        if (hipHostMalloc(&h_rows, (size_t)count * c->B * sizeof(musica_stats), hipHostMallocDefault) != hipSuccess) { h_rows = nullptr; return fail("musica_execute_stream: pinned allocation failed"); }
     }
     HIP_OK(hipStreamSynchronize(c->stream));   // nothing of an earlier call still reads the input buffers
     uint16_t* bufs[2] = {c->d_input, c->d_input2};
@@ -1059,8 +1084,6 @@ int musica_execute_stream(musica_ctx* c, const uint16_t* const* pixels, uint32_t
     const hipError_t e = hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->copy_stream);
     if (ok && e == hipSuccess && stats) memcpy(stats, h_rows, (size_t)count * c->B * sizeof(musica_stats));
-    if (d_rows) hipFree(d_rows);
-    if (h_rows) hipHostFree(h_rows);
     if (e != hipSuccess) return fail("musica_execute_stream: %s", hipGetErrorString(e));
     if (c->profiling) collect_spans(c);
     return ok;
@@ -1195,37 +1218,42 @@ int musica_get_graded(musica_ctx* c, float* dst) {
     return 1;
 }
 
-// saveOutImage: crop margin 10, (uint8_t)(255.0f * (v - 0) / (1 - 0)) (src/vk_processing.cpp:2624-2634).
+// saveOutImage: crop margin 10, (uint8_t)(255.0f * (v - 0) / (1 - 0)) (src/vk_processing.cpp:2624-2634) — on the device
+// (k_out_pixels), then (N - 20)^2 bytes into pinned host memory: 1 B per output pixel instead of the reference's 4 B per input
+// pixel through pageable memory (loadDataFromImage, src/vk_state.cpp:777-803). Returns the pinned buffer (valid until the next call).
+static const uint8_t* out_pixels_pinned(musica_ctx* c, uint32_t idx) {
+    const uint32_t N = (uint32_t)c->N, margin = MUSICA_OUT_MARGIN;
+    if (N <= 2 * margin) { fail("saveOutImage: image too small for the %u-pixel margin", margin); return nullptr; }
+    const size_t nw = N - 2 * margin, bytes = nw * nw;
+    if (!c->d_out8) {
+        if (!dalloc(c, &c->d_out8, bytes)) { fail("saveOutImage: device allocation failed"); return nullptr; }
+        if (hipHostMalloc((void**)&c->h_out8, bytes, hipHostMallocDefault) != hipSuccess) { c->h_out8 = nullptr; fail("saveOutImage: pinned allocation failed"); return nullptr; }
+    }
+    launch_out_pixels(c->stream, c->d_graded + (size_t)idx * c->lv[0].plane, c->lv[0], (int)margin, c->d_out8);
+    hipError_t e = hipMemcpyAsync(c->h_out8, c->d_out8, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { fail("saveOutImage: read-back failed: %s", hipGetErrorString(e)); return nullptr; }
+    return c->h_out8;
+}
+
 int musica_get_out_pixels(musica_ctx* c, uint32_t idx, uint8_t* dst) {
     CHECK_CTX(c); CHECK_IMG(c, idx);
     if (!dst) return fail("musica_get_out_pixels: dst is NULL");
-    const uint32_t N = (uint32_t)c->N, margin = MUSICA_OUT_MARGIN;
-    if (N <= 2 * margin) return fail("musica_get_out_pixels: image too small for the %u-pixel margin", margin);
-    ABI_TRY
-    std::vector<float> g((size_t)N * N);
-    if (!download_plane(c, c->d_graded + (size_t)idx * c->lv[0].plane, c->lv[0], g.data())) return 0;
-    const uint32_t nw = N - 2 * margin;
-    const float maxValue = 1.0f, minValue = 0.0f;
-    for (uint32_t y = 0; y < nw; y++)
-        for (uint32_t x = 0; x < nw; x++) {
-            const float q = 255.0f * (g[(size_t)(y + margin) * N + x + margin] - minValue) / (maxValue - minValue);
-            dst[(size_t)y * nw + x] = (uint8_t)(int32_t)q;
-        }
+    const uint8_t* px = out_pixels_pinned(c, idx);
+    if (!px) return 0;
+    const size_t nw = (size_t)c->N - 2 * MUSICA_OUT_MARGIN;
+    memcpy(dst, px, nw * nw);
     return 1;
-    ABI_CATCH("musica_get_out_pixels")
 }
 
 int musica_save_out_image(musica_ctx* c, uint32_t idx, const char* path) {
     CHECK_CTX(c); CHECK_IMG(c, idx);
     if (!path) return fail("musica_save_out_image: path is NULL");
-    if ((uint32_t)c->N <= 2 * MUSICA_OUT_MARGIN) return fail("musica_save_out_image: image too small for the %u-pixel margin", (unsigned)MUSICA_OUT_MARGIN);
-    ABI_TRY
+    const uint8_t* px = out_pixels_pinned(c, idx);
+    if (!px) return 0;
     const uint32_t nw = (uint32_t)c->N - 2 * MUSICA_OUT_MARGIN;
-    std::vector<uint8_t> buf((size_t)nw * nw);
-    if (!musica_get_out_pixels(c, idx, buf.data())) return 0;
-    if (!musica_write_bmp_gray(path, nw, nw, buf.data())) return fail("failed to write out file");  // :2636-2642
+    if (!musica_write_bmp_gray(path, nw, nw, px)) return fail("failed to write out file");  // :2636-2642
     return 1;
-    ABI_CATCH("musica_save_out_image")
 }
 
 int musica_get_noise_hist(musica_ctx* c, uint32_t idx, uint32_t level, uint32_t* dst) {
@@ -1370,7 +1398,7 @@ int musica_debug_process(musica_ctx* c, uint32_t idx, const char* dir) {
         // expandLowpassImageStates[i] = smooth_upsampled(upsample(previous reconstruction))
         const LevelDesc& lf = c->lv[lvl];
         const float* prev = lvl == c->L - 1 ? c->d_down[c->L - 1] : c->d_recon[lvl + 1];
-        launch_lowpass(c->stream, prev, c->d_scratch, lf, c->lv[lvl + 1], c->B);
+        launch_lowpass(c->stream, prev, c->d_scratch, lf, c->lv[lvl + 1], c->B, c->ref_order);
         std::vector<float> img((size_t)lf.S * lf.S);
         if (!download_plane(c, c->d_scratch + (size_t)idx * lf.plane, lf, img.data())) return 0;
         std::vector<uint8_t> out(img.size());
@@ -1614,7 +1642,12 @@ musica_pipeline* musica_pipeline_create(const musica_params* params, uint32_t de
         const uint32_t n = (depth > 1 && depth < MUSICA_PIPELINE_QUEUES) ? MUSICA_PIPELINE_QUEUES : depth;
         for (uint32_t k = 0; k < n; k++) {
             musica_ctx* c = musica_create(&q);
-            if (!c) { musica_pipeline_destroy(pl); return nullptr; }
+            if (!c) {
+                // the contexts beyond `depth` only exist for the queue calibration: without them (e.g. device memory is short at a
+                // large N) the first `depth` stay and prime() has nothing to choose from
+                if (k >= depth) break;
+                musica_pipeline_destroy(pl); return nullptr;
+            }
             pl->ctx.push_back(c);
         }
         return pl;
@@ -1694,21 +1727,6 @@ int musica_pipeline_step(musica_pipeline* pl, const uint16_t* d_pixels) {
     if (!pl || pl->ctx.empty()) return fail("musica_pipeline_step: no pipeline");
     musica_ctx* c = pl->ctx[pl->steps % pl->ctx.size()];
     if (!musica_execute_device(c, d_pixels ? d_pixels : c->d_input)) return 0;
-    pl->steps++;
-    return 1;
-}
-
-// Host pixels in: the copy into the next context's input buffer is enqueued on that context's stream in front of its step, so it
-// runs under the kernels of the other contexts' steps (the reference uploads through a staging buffer with three queue-idle
-// waits per image, VulkanState::loadDataToImage, src/vk_state.cpp:313-342). `pixels` must stay valid until that context is
-// synchronised or has been handed its next step; pinned memory (musica_host_alloc) moves at the PCIe rate.
-int musica_pipeline_step_host(musica_pipeline* pl, const uint16_t* pixels) {
-    if (!pl || pl->ctx.empty()) return fail("musica_pipeline_step_host: no pipeline");
-    if (!pixels) return fail("musica_pipeline_step_host: pixels is NULL");
-    musica_ctx* c = pl->ctx[pl->steps % pl->ctx.size()];
-    if (hipSetDevice(c->p.device) != hipSuccess) return fail("musica_pipeline_step_host: hipSetDevice failed");
-    HIP_OK(hipMemcpyAsync(c->d_input, pixels, (size_t)c->B * c->N * c->N * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-    if (!musica_execute_device(c, c->d_input)) return 0;
     pl->steps++;
     return 1;
 }

@@ -57,6 +57,8 @@ int main(int argc, char* argv[]) {
     printf("out file %s\n", outFile.c_str());
 
     const auto t0 = std::chrono::high_resolution_clock::now();
+    ASSERT_MSG(musica_device_count() > 0, "failed to initialize vk state");   // main.cpp:45-46 (VulkanState::init): first HIP call = runtime start-up
+    const auto t0h = std::chrono::high_resolution_clock::now();
     musica_params p;
     memset(&p, 0, sizeof(p));
     p.image_size = imageSize;
@@ -66,6 +68,7 @@ int main(int argc, char* argv[]) {
     p.flags = flags;
     musica_ctx* ctx = musica_create(&p);
     ASSERT_MSG(ctx != nullptr, "failed to initialize vk processing");  // main.cpp:51 (message kept)
+    const auto t0c = std::chrono::high_resolution_clock::now();
 
     std::vector<uint16_t> pixels((size_t)imageSize * imageSize);
     {
@@ -89,7 +92,10 @@ int main(int argc, char* argv[]) {
     };
     // the reference prints one per-stage timing line per execute (src/vk_processing.cpp:2585-2595)
     printf("init: %.2f \t exec: %.2f \t save: %.2f \t tot: %.2f \n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t0, t3));
+    // init = HIP runtime start-up + device allocation (create) and reading the raw file; exec = H2D + the pipeline + the final wait
+    printf("hip start-up: %.2f \t create: %.2f \t read: %.2f \n", ms(t0, t0h), ms(t0h, t0c), ms(t0c, t1));
 
     musica_destroy(ctx);  // main.cpp:85-86
+    printf("cleanup: %.2f \n", ms(t3, std::chrono::high_resolution_clock::now()));
     return 0;
 }

@@ -160,7 +160,6 @@ ABI = {
     "musica_pipeline_prime": (C.c_int, [_VP, C.c_uint32]),
     "musica_pipeline_calibration": (C.c_uint32, [_VP, _F32P]),
     "musica_pipeline_step": (C.c_int, [_VP, _VP]),
-    "musica_pipeline_step_host": (C.c_int, [_VP, _U16P]),
     "musica_pipeline_last": (_VP, [_VP]),
     "musica_pipeline_sync": (C.c_int, [_VP]),
     "musica_last_error": (C.c_char_p, []),
@@ -546,8 +545,7 @@ class MusicaProcessing:
 
 class MusicaPipeline:
     """The C ABI's steps-in-flight object (musica_pipeline_*, include/musica.h): `depth` one-stream contexts of one GPU whose
-    steps alternate, with the choice of hardware queues made by musica_pipeline_prime(). batch.ShardPipeline is the same
-    thing written in Python on top of MusicaProcessing (and is what bench.py uses); this class is the native one."""
+    steps alternate, with the choice of hardware queues made by musica_pipeline_prime() (what bench.py times)."""
 
     def __init__(self, imageSize, levels=0, batch=1, depth=3, flags=0, device=0):
         self._lib = load_library()
@@ -557,17 +555,25 @@ class MusicaPipeline:
             raise RuntimeError("musica_pipeline_create failed: " + last_error())
         self._device = int(device)
         self.depth = int(depth)
+        self._pixels = int(batch) * int(imageSize) * int(imageSize)
+        self._borrowed = []
 
     def _ok(self, rc, what):
         if rc != 1:
             raise RuntimeError("%s failed: %s" % (what, last_error()))
 
     def upload(self, images):
+        """The same batch (batch x N x N uint16) into every context's input buffer."""
         px = np.ascontiguousarray(images, dtype=np.uint16)
+        if px.size != self._pixels:      # the C side copies batch * N * N pixels whatever it is handed
+            raise ValueError("expected %d pixels (batch x N x N), got %d" % (self._pixels, px.size))
         self._ok(self._lib.musica_pipeline_upload(self._p, px.ctypes.data_as(_U16P)), "musica_pipeline_upload")
 
     def prime(self, calibration_steps=0):
         self._ok(self._lib.musica_pipeline_prime(self._p, int(calibration_steps)), "musica_pipeline_prime")
+        for w in self._borrowed:         # prime() destroys the contexts outside the window it keeps: wrappers handed out before it are void
+            w._h = None
+        self._borrowed = []
 
     def calibration(self):
         """{first context of the window: ms per step} of the windows prime() timed ({} when there was nothing to choose)."""
@@ -579,16 +585,12 @@ class MusicaPipeline:
         h = self._lib.musica_pipeline_context(self._p, int(k))
         if not h:
             raise IndexError(last_error())
-        return MusicaProcessing._borrow(h, self._device)
+        w = MusicaProcessing._borrow(h, self._device)
+        self._borrowed.append(w)
+        return w
 
     def step(self, d_pixels=None):
         self._ok(self._lib.musica_pipeline_step(self._p, d_pixels), "musica_pipeline_step")
-
-    def step_host(self, images):
-        """One step on host pixels (uint16 array, C-contiguous; keep it alive until the pipeline is synchronised)."""
-        if not (isinstance(images, np.ndarray) and images.dtype == np.uint16 and images.flags["C_CONTIGUOUS"]):
-            raise TypeError("step_host needs a C-contiguous uint16 array (it is read asynchronously)")
-        self._ok(self._lib.musica_pipeline_step_host(self._p, images.ctypes.data_as(_U16P)), "musica_pipeline_step_host")
 
     def last(self):
         h = self._lib.musica_pipeline_last(self._p)

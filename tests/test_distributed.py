@@ -170,65 +170,3 @@ def test_bench_rank_mismatch_is_refused_without_a_gpu():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=120, cwd=root)
     assert r.returncode != 0 and "WORLD_SIZE (2) != --gpus (8)" in r.stderr
-
-
-def test_shard_pipeline_keeps_the_fastest_window_of_queues(monkeypatch):
-    """batch.ShardPipeline's host logic without a GPU: four stub contexts stand for the four hardware queues, two of which
-    (2 and 3) do not run side by side; prime() must time every cyclic window of three, keep {3, 0, 1} or {0, 1, 2} — never a
-    window holding both 2 and 3 — destroy the fourth context, re-upload per-context images in step order and leave the
-    round-robin at step 0."""
-    import time
-    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd import batch
-
-    created, log = [], []
-
-    class Stub:
-        pending = set()
-
-        def __init__(self, device=0):
-            self.qid = len(created)
-            self.alive = True
-            self.images = None
-            created.append(self)
-
-        def init(self, n, levels=0, batch=1, flags=0):
-            self.flags = flags
-            return True
-
-        def upload(self, images):
-            self.images = images
-
-        def execute_device(self, d_pixels=None):
-            assert self.alive
-            Stub.pending.add(self.qid)
-            log.append(self.qid)
-            return True
-
-        def sync(self):
-            if Stub.pending:
-                time.sleep(0.004 if {2, 3} <= Stub.pending else 0.001)   # the slow pair serialises
-                Stub.pending = set()
-
-        def cleanup(self):
-            self.alive = False
-
-    monkeypatch.setattr(batch, "MusicaProcessing", Stub)
-    pipe = batch.ShardPipeline(64, levels=3, batch=2, depth=3)
-    assert len(pipe.contexts) == 4 and all(c.flags & batch.FLAG_LINEAR for c in created)
-    imgs = ["a", "b", "c"]
-    pipe.upload(imgs)
-    pipe.prime(calibration_steps=3)
-    kept = [c.qid for c in pipe.contexts]
-    assert kept in ([0, 1, 2], [3, 0, 1]) and sorted(pipe.calibration) == [0, 1, 2, 3]
-    assert pipe.calibration[1] > min(pipe.calibration.values()) and pipe.calibration[2] > min(pipe.calibration.values())
-    assert [c.alive for c in created].count(False) == 1 and all(c.alive for c in pipe.contexts)
-    assert [c.images for c in pipe.contexts] == imgs and pipe.steps == 0
-    del log[:]
-    for _ in range(5):
-        pipe.step()
-    assert log == [kept[k % 3] for k in range(5)] and pipe.last() is pipe.contexts[1]
-    pipe.cleanup()
-    assert not any(c.alive for c in created)
-    # depth 1 and calibrate=False create exactly what they are asked for
-    assert len(batch.ShardPipeline(64, depth=1).contexts) == 1
-    assert len(batch.ShardPipeline(64, depth=3, calibrate=False).contexts) == 3
