@@ -1,6 +1,6 @@
 """Window of a rocprofv3 kernel_trace.csv of `bench.py` with contexts in flight: which queue ran what, and how much of the
 window had at least one / no kernel resident.  python devtools/inflight_timeline.py <kernel_trace.csv> [window_us]
-The window starts at the middle k_clear of the longest run of steps that alternate over queues (the timed steps)."""
+The window starts at the middle k_minmax_u16 of the longest run of steps that alternate over queues (the timed steps)."""
 import csv
 import sys
 
@@ -8,8 +8,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 win = float(sys.argv[2]) if len(sys.argv) > 2 else 800.0
 ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']),
              r['Kernel_Name'].split('(')[0].replace('void musica::', '').replace('musica::', ''), r.get('Queue_Id')) for r in rows)
-clears = [k for k in ks if k[2] == 'k_clear']
-# the timed steps of the pipeline: the longest run of k_clear launches in which consecutive ones sit on different queues
+clears = [k for k in ks if k[2] == 'k_minmax_u16']
+# the timed steps of the pipeline: the longest run of k_minmax_u16 launches in which consecutive ones sit on different queues
 runs, i = [], 0
 while i < len(clears) - 1:
     j = i

@@ -61,38 +61,103 @@ __device__ __forceinline__ void minmax_acc(us2& mn, us2& mx, const uint4& q) {  
     }
 }
 
-__global__ __launch_bounds__(256) void k_minmax_u16(const uint16_t* __restrict__ px, size_t count, uint32_t* __restrict__ minmax) {
-    const uint16_t* p = px + (size_t)blockIdx.z * count;
+// Two stages, no same-address atomics (a block used to end with an atomic pair on the image's two words; those retire ~11 ns
+// apart, which capped the grid at 256 blocks per image and left a serial tail): every block reduces its share — one trip of
+// kMinMaxLoads 16-byte loads per lane, all in flight at once — and stores ONE word {min | max << 16} into its own slot; the
+// block that draws the last ticket of its image folds the slots into the two words img_normalize.comp reads and puts the ticket
+// back to 0 for the next launch. Slot hand-off across XCDs: sc1 (write-through) store -> vmcnt(0) -> ticket add by the same lane;
+// last block: barrier -> sc1 loads of every slot. The launch also zeroes the image's histograms (the vkCmdClearColorImage
+// calls of src/vk_processing.cpp:2153-2162): every kernel that adds to or reads them runs behind this one.
+constexpr int kMinMaxLoads = 8;
+constexpr int kMinMaxThreads = 1024;
+constexpr int kMinMaxMaxBlocks = 4096;   // slots per image (launch_minmax uses at most 512)
+constexpr int kTicketStride = 32;        // words between the tickets of two images: one 128-byte line each (same-line atomics serialise)
+struct ClearArgs {
+    uint32_t* noise_hist;    // [batch][4][2048] or null
+    uint32_t* grad_hist;     // [batch][1024] or null
+    uint32_t* grad_hist_b;   // [batch][1024] or null
+    uint32_t* gzero;         // [batch] or null
+    uint32_t* clahe_hist;    // [batch][4 * 4 * 256] or null
+};
+__device__ __forceinline__ void zero_words(uint32_t* p, int n, int first, int stride) {
+    if (!p) return;
+    for (int i = first; i < n; i += stride) p[i] = 0u;
+}
+template <int LOADS>
+__global__ __launch_bounds__(kMinMaxThreads) void k_minmax_u16(const uint16_t* __restrict__ px, size_t count, uint32_t* __restrict__ minmax,
+                                                              uint32_t* __restrict__ slots, uint32_t* __restrict__ ticket, ClearArgs ca) {
+    const int img = blockIdx.z, nb = gridDim.x;
+    {
+        const int first = blockIdx.x * blockDim.x + threadIdx.x, stride = nb * blockDim.x;
+        zero_words(ca.noise_hist ? ca.noise_hist + (size_t)img * 4 * MUSICA_NOISE_BINS : nullptr, 4 * MUSICA_NOISE_BINS, first, stride);
+        zero_words(ca.grad_hist ? ca.grad_hist + (size_t)img * MUSICA_GRAD_BINS : nullptr, MUSICA_GRAD_BINS, first, stride);
+        zero_words(ca.grad_hist_b ? ca.grad_hist_b + (size_t)img * MUSICA_GRAD_BINS : nullptr, MUSICA_GRAD_BINS, first, stride);
+        zero_words(ca.gzero ? ca.gzero + img : nullptr, 1, first, stride);
+        constexpr int kClaheWords = MUSICA_CLAHE_TILES * MUSICA_CLAHE_TILES * MUSICA_CLAHE_BINS;
+        zero_words(ca.clahe_hist ? ca.clahe_hist + (size_t)img * kClaheWords : nullptr, kClaheWords, first, stride);
+    }
+    const uint16_t* p = px + (size_t)img * count;
     const size_t nvec = (((uintptr_t)p & 15u) == 0) ? count / 8 : 0;  // 8 pixels per 16-byte load
     const uint4* pv = reinterpret_cast<const uint4*>(p);
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    // a block reads CONTIGUOUS chunks of LOADS * blockDim 16-byte vectors (its lanes' successive loads one block-width apart): with the
+    // loads of a lane a whole grid-width apart — a power-of-two number of bytes — they all fell into the same memory channels
+    // (3.1 TB/s at 8 x 2048^2; this form: see DESIGN.md section 6)
+    const size_t chunk = (size_t)LOADS * blockDim.x, stride = (size_t)nb * chunk;
     us2 mn2 = {0xFFFFu, 0xFFFFu}, mx2 = {0u, 0u};
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < nvec; i += 4 * stride) {   // four independent 16-byte loads in flight per lane (eight: no change, 22 us)
-        const uint4 q0 = pv[i], q1 = pv[i + stride], q2 = pv[i + 2 * stride], q3 = pv[i + 3 * stride];
-        minmax_acc(mn2, mx2, q0);
-        minmax_acc(mn2, mx2, q1);
-        minmax_acc(mn2, mx2, q2);
-        minmax_acc(mn2, mx2, q3);
+    size_t i = (size_t)blockIdx.x * chunk + threadIdx.x;
+    for (; i + (LOADS - 1) * (size_t)blockDim.x < nvec; i += stride) {
+        uint4 q[LOADS];
+#pragma unroll
+        for (int k = 0; k < LOADS; k++) q[k] = pv[i + (size_t)k * blockDim.x];
+#pragma unroll
+        for (int k = 0; k < LOADS; k++) minmax_acc(mn2, mx2, q[k]);
     }
-    for (; i < nvec; i += stride) minmax_acc(mn2, mx2, pv[i]);
+    if (i < nvec) {   // the image's last, partial chunk
+#pragma unroll
+        for (int k = 0; k < LOADS; k++)
+            if (i + (size_t)k * blockDim.x < nvec) minmax_acc(mn2, mx2, pv[i + (size_t)k * blockDim.x]);
+    }
     uint32_t mn = min((uint32_t)mn2.x, (uint32_t)mn2.y), mx = max((uint32_t)mx2.x, (uint32_t)mx2.y);
-    for (size_t i = nvec * 8 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t v = p[i];
+    for (size_t k = nvec * 8 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (size_t)nb * blockDim.x) {
+        const uint32_t v = p[k];
         mn = min(mn, v);
         mx = max(mx, v);
     }
     mn = wave_min(mn);
     mx = wave_max(mx);
-    __shared__ uint32_t smn[4], smx[4];
+    const int kWaves = blockDim.x / 64;
+    __shared__ uint32_t smn[kMinMaxThreads / 64], smx[kMinMaxThreads / 64];
+    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) { smn[wv] = mn; smx[wv] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        mn = min(min(smn[0], smn[1]), min(smn[2], smn[3]));
-        mx = max(max(smx[0], smx[1]), max(smx[2], smx[3]));
-        atomicMin(&minmax[kMinMaxStride * blockIdx.z], mn);
-        atomicMax(&minmax[kMinMaxStride * blockIdx.z + kMaxWord], mx);
+        for (int k = 1; k < kWaves; k++) { mn = min(mn, smn[k]); mx = max(mx, smx[k]); }
+        // write-through (sc1) slot store, drained, then the ticket; the last block reads every slot with sc1 loads: no agent
+        // release / acquire fence (a release per block writes back the whole XCD L2: 128 us per launch with 4096 blocks)
+        __hip_atomic_store(&slots[(size_t)img * kMinMaxMaxBlocks + blockIdx.x], mn | (mx << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t old = __hip_atomic_fetch_add(&ticket[(size_t)img * kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == (uint32_t)(nb - 1);
+    }
+    __syncthreads();   // the other wavefronts load only behind the barrier the ticket holder joined after its add returned
+    if (!s_last) return;   // block-uniform
+    mn = 0xFFFFu; mx = 0u;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+        const uint32_t v = __hip_atomic_load(&slots[(size_t)img * kMinMaxMaxBlocks + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mn = min(mn, v & 0xFFFFu);
+        mx = max(mx, v >> 16);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    __syncthreads();   // smn / smx were read by thread 0 above
+    if (lane == 0) { smn[wv] = mn; smx[wv] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kWaves; k++) { mn = min(mn, smn[k]); mx = max(mx, smx[k]); }
+        minmax[kMinMaxStride * img] = mn;
+        minmax[kMinMaxStride * img + kMaxWord] = mx;
+        ticket[(size_t)img * kTicketStride] = 0u;   // the next launch counts from 0 again (launches of one context are ordered)
     }
 }
 
@@ -223,6 +288,94 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __r
             load_sraw(raw, bb, roff(y + 3), g);  // rows past the image carry an out-of-range offset: no access
             sdev_row<HIST, A8>(w0, w1, w2, w3, w4, g, S, y, cov, sdev + (size_t)y * pitch, db, (uint32_t)y * rb, lh, alive, start);
             w0 = w1; w1 = w2; w2 = w3; w3 = w4;
+        }
+    }
+    __syncthreads();
+    hist_lds_flush(lh, hist + (size_t)img * hist_stride);
+}
+
+// ---- K10 + K11, one 16-row histogram run per workgroup ------------------------------------------------------
+// The march above gives a wavefront a whole 16-row run (the `break` of noise_hist.comp:29-39 makes a run an ordered scan), i.e.
+// 20 dependent row trips: 16 - 17 us per launch however small the level, and 16 rows x ~290 vector instructions would cost a
+// lone wavefront ~9 us even with every load in flight. Here the four wavefronts of a workgroup share ONE run of 512 columns:
+// each takes 4 of its rows, requests its 8 input rows at once (one round of latency), computes its 4 sdev rows and the
+// per-row "bin != 0" lane masks; the wavefronts then exchange, through LDS and one barrier, the AND of their masks per owned
+// column — the run of a column is alive at row r exactly when every earlier row of the run had a non-zero bin — and add
+// their texels to the workgroup's LDS histogram. Same expressions (sdev_values, musica_noise_bin) as the march: same bits.
+// Input rows are read twice (8 per 4 instead of 20 per 16), from the XCD's L2 the second time.
+constexpr int kRunRowsPerWave = kHistArea / kWavesPerBlock;   // 4
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <bool A8>
+__global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_run(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
+                                                                 size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov, int swz) {
+    __shared__ uint32_t lh[kHistLdsWords];
+    __shared__ unsigned long long nzw[kWavesPerBlock][8];
+    hist_lds_clear(lh);
+    const int img = blockIdx.z;
+    const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
+    sdev += (size_t)img * plane;
+    const Buf db = make_buf(sdev, plane * 4);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const Tile tile = xcd_tile(swz);
+    const int y0 = tile.segblock * kHistArea + wave * kRunRowsPerWave;   // wave-uniform
+    const SCfg g = make_scfg(tile.strip, lane, S);
+    const uint32_t rb = (uint32_t)pitch * 4u;
+    auto roff = [&](int row) -> uint32_t { return (row >= 0 && row < S) ? (uint32_t)row * rb : kOob; };
+    unsigned long long nz[kRunRowsPerWave][8];
+    int bin[kRunRowsPerWave][8];
+    unsigned long long mine[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) mine[j] = ~0ull;
+    const int nrows = min(max(S - y0, 0), kRunRowsPerWave);   // rows of this wavefront inside the image
+    if (nrows > 0) {
+        SRaw raw[kRunRowsPerWave + 4];
+#pragma unroll
+        for (int k = 0; k < kRunRowsPerWave + 4; k++) load_sraw(raw[k], bb, roff(y0 - 2 + k), g);
+        SRow w[kRunRowsPerWave + 4];
+#pragma unroll
+        for (int k = 0; k < kRunRowsPerWave + 4; k++) square_srow<A8>(w[k], raw[k], g, S);
+#pragma unroll
+        for (int r = 0; r < kRunRowsPerWave; r++) {
+            if (r < nrows) {   // wave-uniform
+                float s[8];
+                sdev_values(w[r], w[r + 1], w[r + 2], w[r + 3], w[r + 4], g, s);
+                sdev_store<A8>(s, g, sdev + (size_t)(y0 + r) * pitch, db, (uint32_t)(y0 + r) * rb);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    bin[r][j] = musica_noise_bin(s[j]);      // 0 = break (noise_hist.comp:29, :33, :39)
+                    nz[r][j] = __ballot(bin[r][j] != 0);
+                    mine[j] &= nz[r][j];
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) nzw[wave][j] = mine[j];
+    }
+    __syncthreads();   // the cleared histogram and every wavefront's masks
+    if (nrows > 0 && y0 < cov) {   // the dispatch covers whole runs (cov is a multiple of 512)
+        const uint32_t copy_b = (uint32_t)((lane % kHistCopies) * kHistCopyStride) * 4u, scratch_b = (uint32_t)(kHistCopies * kHistCopyStride + lane) * 4u;
+        unsigned long long alive[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            alive[j] = __ballot(j < g.valid && g.c + j < cov);   // columns outside the image / the coverage start dead
+            for (int v = 0; v < wave; v++) alive[j] &= uniform64(nzw[v][j]);   // the same value in every lane: back into scalar registers
+        }
+#pragma unroll
+        for (int r = 0; r < kRunRowsPerWave; r++) {
+            if (r < nrows) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    alive[j] &= nz[r][j];
+                    const uint32_t addr = select_by_lane_mask(alive[j], copy_b + (uint32_t)bin[r][j] * 4u, scratch_b);
+                    atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lh) + addr), 1u);   // :45
+                }
+            }
         }
     }
     __syncthreads();
@@ -549,15 +702,20 @@ void launch_clear(hipStream_t st, uint32_t* minmax, uint32_t* noise_hist, uint32
     hipLaunchKernelGGL(k_clear, dim3((n + 255) / 256), dim3(256), 0, st, minmax, noise_hist, grad_hist, clahe_hist, batch, grad_hist_b, gzero);
 }
 
-void launch_minmax(hipStream_t st, const uint16_t* px, int N, uint32_t* minmax, int batch) {
+void launch_minmax(hipStream_t st, const uint16_t* px, int N, uint32_t* minmax, uint32_t* slots, uint32_t* ticket, int batch,
+                   uint32_t* noise_hist, uint32_t* grad_hist, uint32_t* grad_hist_b, uint32_t* gzero, uint32_t* clahe_hist) {
     const size_t count = (size_t)N * N;
-    // every block ends with one atomic pair on the image's two words, and same-address atomics retire ~11 ns apart:
-    // at most 256 blocks per image (measured on one 2048^2 image: 2048 blocks 29 us, 512 blocks 12 us, 256 blocks 9 us)
-    static const int forced = getenv("MUSICA_MINMAX_BLOCKS") ? atoi(getenv("MUSICA_MINMAX_BLOCKS")) : 0;
-    const int per_image = forced > 0 ? forced : std::min(256, std::max(32, 2048 / std::max(batch, 1)));
-    int blocks = (int)std::min<size_t>((count / 8 + 255) / 256, (size_t)per_image);
+    // one trip of kMinMaxLoads loads per lane (2048^2: 64 blocks of 128 KiB) up to 512 blocks per image, then more trips: a block
+    // ends with one returning atomic on its image's ticket, ~11 ns apart on one address
+    static const int threads = getenv("MUSICA_MM_THREADS") ? atoi(getenv("MUSICA_MM_THREADS")) : kMinMaxThreads;
+    static const int loads = getenv("MUSICA_MM_LOADS") ? atoi(getenv("MUSICA_MM_LOADS")) : kMinMaxLoads;
+    static const int maxb = getenv("MUSICA_MM_BLOCKS") ? atoi(getenv("MUSICA_MM_BLOCKS")) : 512;
+    size_t blocks = (count / 8 + (size_t)threads * loads - 1) / ((size_t)threads * loads);
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_minmax_u16, dim3(blocks, 1, batch), dim3(256), 0, st, px, count, minmax);
+    if (blocks > (size_t)maxb) blocks = maxb;
+    ClearArgs ca{noise_hist, grad_hist, grad_hist_b, gzero, clahe_hist};
+    if (loads == 4) hipLaunchKernelGGL(k_minmax_u16<4>, dim3((unsigned)blocks, 1, batch), dim3(threads), 0, st, px, count, minmax, slots, ticket, ca);
+    else hipLaunchKernelGGL(k_minmax_u16<8>, dim3((unsigned)blocks, 1, batch), dim3(threads), 0, st, px, count, minmax, slots, ticket, ca);
 }
 
 void launch_normalize(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, const uint32_t* minmax,
@@ -575,6 +733,12 @@ void launch_sqrt(hipStream_t st, const uint16_t* px, float* out, const LevelDesc
 void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov,
                       int batch, int rows_per_wave) {
     const int strips = (l.S + kStripCols - 1) / kStripCols;
+    if (rows_per_wave <= 0) {   // one 16-row run per workgroup (k_sdev_hist_run)
+        const dim3 grid(strips, (l.S + kHistArea - 1) / kHistArea, batch);
+        if ((l.S & 7) == 0) hipLaunchKernelGGL((k_sdev_hist_run<true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, xcd_swizzle_on());
+        else hipLaunchKernelGGL((k_sdev_hist_run<false>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, xcd_swizzle_on());
+        return;
+    }
     const int segs = (l.S + rows_per_wave - 1) / rows_per_wave;
     const dim3 grid(strips, (segs + kWavesPerBlock - 1) / kWavesPerBlock, batch);
     if ((l.S & 7) == 0) hipLaunchKernelGGL((k_sdev_hist_pf<true, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave, xcd_swizzle_on());

@@ -75,7 +75,12 @@ void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, 
 void launch_exp_band(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch);
 // kernels_analysis.hip
 void launch_clear(hipStream_t st, uint32_t* minmax, uint32_t* noise_hist, uint32_t* grad_hist, uint32_t* clahe_hist, int batch, uint32_t* grad_hist_b = nullptr, uint32_t* gzero = nullptr);
-void launch_minmax(hipStream_t st, const uint16_t* px, int N, uint32_t* minmax, int batch);
+// min / max of the raw pixels (slots: [batch][kMinMaxSlots] words, ticket: [batch] words, zero at first use) and, where the pointers are
+// given, the clears of src/vk_processing.cpp:2153-2162 in the same launch
+constexpr int kMinMaxSlots = 4096;
+void launch_minmax(hipStream_t st, const uint16_t* px, int N, uint32_t* minmax, uint32_t* slots, uint32_t* ticket, int batch,
+                   uint32_t* noise_hist = nullptr, uint32_t* grad_hist = nullptr, uint32_t* grad_hist_b = nullptr, uint32_t* gzero = nullptr,
+                   uint32_t* clahe_hist = nullptr);
 void launch_normalize(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, const uint32_t* minmax, int min_chain_exact, int batch);
 void launch_sqrt(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, int batch);
 void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch, int rows_per_wave);

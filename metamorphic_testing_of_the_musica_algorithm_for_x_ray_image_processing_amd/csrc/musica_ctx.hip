@@ -90,6 +90,8 @@ struct musica_ctx {
     hipEvent_t ev_copied[2], ev_consumed[2];
     const uint16_t* cur_input;
     uint32_t* d_minmax;
+    uint32_t* d_mm_slots;      // [B][kMinMaxSlots]: per-block {min | max << 16} of k_minmax_u16
+    uint32_t* d_mm_ticket;     // [B]: its arrival counters (self-resetting)
     float* d_norm;
     float* d_down[MUSICA_MAX_LEVELS];
     float* d_band[MUSICA_MAX_LEVELS];
@@ -205,6 +207,14 @@ static int pick_rows(int dflt, int min_rows, int S, int rows_total, int batch, i
     }
     return rpw < min_rows ? min_rows : rpw;
 }
+// Rows per wavefront of the sdev + noise-histogram launch of level i; 0 = one 16-row run per workgroup (k_sdev_hist_run), the
+// form for every launch that cannot fill the chip with 16-row marches (levels >= 1; MUSICA_SDEV_RUN=0 / 1: never / always).
+static int sdev_rows_default(const musica_ctx* c, int i, int batch) {
+    const int mode = env_int("MUSICA_SDEV_RUN", -1);
+    if (mode == 1 || (mode < 0 && i >= 1)) return 0;
+    return pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, batch);
+}
+
 // How many independent groups the batch is cut into: MUSICA_GROUPS, default 1. Measured on MI355X at
 // 8 x 2048 x 2048 ("Image groups"): 1 group 0.565 ms, 2 groups 0.586 ms, 4 groups 0.78 ms per step —
 // the groups start in lockstep, so their small kernels meet each other instead of the other group's
@@ -243,6 +253,8 @@ static musica_ctx* make_view(const musica_ctx* c, int i0, int nb) {
     v->d_input += o * NN;
     v->cur_input = v->d_input;
     v->d_minmax += o * kMinMaxStride;
+    v->d_mm_slots += o * kMinMaxSlots;
+    v->d_mm_ticket += o * kMinMaxStride;
     v->d_norm += o * c->lv[0].plane;
     for (int i = 0; i < c->L; i++) {
         v->d_down[i] += o * c->lv[i + 1].plane;
@@ -276,7 +288,7 @@ static musica_ctx* make_view(const musica_ctx* c, int i0, int nb) {
         v->rows_reduce[i] = pick_rows(c->reduce_rows, 1, c->lv[i].S, c->lv[i + 1].S, nb);
         v->rows_band[i] = pick_rows(c->band_rows, 1, c->lv[i].S, c->lv[i + 1].S, nb);
         v->rows_expand[i] = pick_rows(c->expand_rows, 1, c->lv[i].S, c->lv[i + 1].S, nb);
-        if (i <= MUSICA_CNR_LEVEL) v->rows_sdev[i] = pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, nb);
+        if (i <= MUSICA_CNR_LEVEL) v->rows_sdev[i] = sdev_rows_default(c, i, nb);
         v->rows_rb[i] = pick_rows(16, 1, c->lv[i].S, c->lv[i + 1].S, nb);
     }
     return v;
@@ -451,6 +463,8 @@ static musica_ctx* create_impl(const musica_params* params) {
                  cnr_scale(c->lv[0].S, c->lv[MUSICA_CNR_LEVEL].S) == 8;
     ok = ok && dalloc(c, &c->d_input, B * N * N);
     ok = ok && dalloc(c, &c->d_minmax, B * kMinMaxStride);
+    ok = ok && dalloc(c, &c->d_mm_slots, B * kMinMaxSlots);
+    ok = ok && dalloc(c, &c->d_mm_ticket, B * kMinMaxStride);   // one 128-byte line per image
     ok = ok && dalloc(c, &c->d_norm, B * c->lv[0].plane);
     for (int i = 0; i < c->L && ok; i++) {
         ok = ok && dalloc(c, &c->d_down[i], B * c->lv[i + 1].plane);
@@ -496,7 +510,7 @@ static musica_ctx* create_impl(const musica_params* params) {
         c->rows_reduce[i] = pick_rows(c->reduce_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
         c->rows_band[i] = pick_rows(c->band_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
         c->rows_expand[i] = pick_rows(c->expand_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
-        if (i <= MUSICA_CNR_LEVEL) c->rows_sdev[i] = pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, c->B);
+        if (i <= MUSICA_CNR_LEVEL) c->rows_sdev[i] = sdev_rows_default(c, i, c->B);
         c->rows_rb[i] = pick_rows(env_int("MUSICA_RB_ROWS", 16), 1, c->lv[i].S, c->lv[i + 1].S, c->B);
     }
     const bool tune = !(params->flags & MUSICA_FLAG_NO_AUTOTUNE) && env_int("MUSICA_AUTOTUNE", 1) && !c->generic;
@@ -574,8 +588,13 @@ static void collect_spans(musica_ctx* c) {
 static const float* level_input(musica_ctx* c, int i) { return i == 0 ? c->d_norm : c->d_down[i - 1]; }  // src/vk_processing.cpp:758-761
 
 // stage "norm" (src/vk_processing.cpp:2182-2222)
-static void enqueue_norm(musica_ctx* c) {
-    { Span sp(c, MUSICA_KERNEL_MINMAX); launch_minmax(c->stream, c->cur_input, c->N, c->d_minmax, c->B); }
+// with_clears: the launch also zeroes the histograms (src/vk_processing.cpp:2153-2162)
+static void enqueue_norm(musica_ctx* c, bool with_clears) {
+    {
+        Span sp(c, MUSICA_KERNEL_MINMAX);
+        if (with_clears) launch_minmax(c->stream, c->cur_input, c->N, c->d_minmax, c->d_mm_slots, c->d_mm_ticket, c->B, c->d_noise_hist, c->d_grad_hist, c->d_grad_hist_b, c->d_gzero, c->d_clahe_hist);
+        else launch_minmax(c->stream, c->cur_input, c->N, c->d_minmax, c->d_mm_slots, c->d_mm_ticket, c->B);
+    }
     c->norm_valid = false;
     if (!c->fuse_u16 || (c->d_clahe_hist && !c->clahe_raw)) {  // a CLAHE block that reads the stored normalized image through k_relevant
         Span sp(c, MUSICA_KERNEL_NORMALIZE);
@@ -740,8 +759,8 @@ static void enqueue_gradation(musica_ctx* c, bool fused) {
 
 // Three-stream form of the dispatch script (dag == 1, the default for batches and large images). The reference submits
 // everything to one in-order queue; the data dependences allow more:
-//   stream : clear minmax R0 R1 | B0 S0 B1 S1 (wait side, side1) E3 curves E2 E1 E0 gradation
-//   side   :                    | R2 .. R(L-1) B2 B3 . B4 .. E(L-1) .. E4 S3
+//   stream : minmax (+ clears) R0 R1 | B0 S0 B1 S1 (wait side, side1) curves E2 E1 E0 gradation
+//   side   :                         | R2 .. R(L-1) B2 B3 . B4 .. E(L-1) .. E4 S3 E3
 //   side1  :                                    (B2) S2
 // Small kernels only get wave slots in the tails of a chip-filling kernel beside them (rocprofv3 timeline: a 6 us reduce waits
 // 30 us behind band 0; sdev 2 and sdev 3 sit out sdev 0, whose 4096 wavefronts hold every slot for the whole launch), so the
@@ -764,8 +783,7 @@ static void enqueue_gradation(musica_ctx* c, bool fused) {
 static void enqueue_dag(musica_ctx* c) {
     const int L = c->L;
     c->cur = c->stream;
-    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B, c->d_grad_hist_b, c->d_gzero);  // :2153-2162
-    enqueue_norm(c);
+    enqueue_norm(c, true);   // with the clears of :2153-2162
     // reduce (+ band, where the fused march applies: k_reduce_band) of levels 0 and 1
     const bool rb0 = rb_level(c, 0), rb1 = rb_level(c, 1);
     if (rb0) { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_band(c, 0, c->rows_rb[0]); }
@@ -793,11 +811,12 @@ static void enqueue_dag(musica_ctx* c) {
         run_expand_level(c, lvl, c->rows_expand[lvl]);
     }
     { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, MUSICA_CNR_LEVEL, c->rows_sdev[MUSICA_CNR_LEVEL]); }
+    // expand 3 reads no curve (two-point constant gain, GAIN_RANGE) and no cnr: it stays in the side chain, off the main stream's tail
+    { Span sp(c, MUSICA_KERNEL_EXPAND_REST); run_expand_level(c, MUSICA_CNR_LEVEL, c->rows_expand[MUSICA_CNR_LEVEL]); }
     hipEventRecord(c->ev_join, c->side);
     c->cur = c->stream;
     hipStreamWaitEvent(c->stream, c->ev_s1, 0);
     hipStreamWaitEvent(c->stream, c->ev_join, 0);
-    { Span sp(c, MUSICA_KERNEL_EXPAND_REST); run_expand_level(c, MUSICA_CNR_LEVEL, c->rows_expand[MUSICA_CNR_LEVEL]); }
     {   // curves of every level + cnr of level 3 in one launch (kernels_analysis.hip k_curves_cnr)
         Span sp(c, MUSICA_KERNEL_CURVES);
         launch_curves_cnr(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
@@ -813,8 +832,7 @@ static void enqueue_dag(musica_ctx* c) {
 // One in-order stream, the order of the reference's command buffer (dag == 0).
 static void enqueue_linear(musica_ctx* c) {
     c->cur = c->stream;
-    launch_clear(c->stream, c->d_minmax, c->d_noise_hist, c->d_grad_hist, c->d_clahe_hist, c->B, c->d_grad_hist_b, c->d_gzero);  // :2153-2162
-    enqueue_norm(c);
+    enqueue_norm(c, true);   // with the clears of :2153-2162
     enqueue_reduce(c);
     enqueue_analysis(c);
     enqueue_expand(c, true);
@@ -945,7 +963,7 @@ static void autotune(musica_ctx* c) {
     const int reps = 3;
     static const int cand_reduce[] = {4, 8, 12, 16, 32};
     static const int cand_pair[] = {2, 4, 8, 16};   // band / expand count coarse rows (two fine rows each)
-    static const int cand_sdev[] = {16, 32, 64};
+    static const int cand_sdev[] = {0, 16, 32, 64};   // 0: one run per workgroup
     for (int i = 0; i < c->L; i++) {
         if (c->lv[i].S < 512 || (c->lv[i].S % 8) != 0) continue;   // small levels are launch-bound: keep the heuristic
         static const int cand_rb[] = {4, 8, 16, 32, 64};
@@ -954,7 +972,7 @@ static void autotune(musica_ctx* c) {
             {&c->rows_reduce[i], cand_reduce, 5, run_reduce_level, !rb_level(c, i) && i == 0 && c->fuse_u16},
             {&c->rows_band[i], cand_pair, 4, run_band_level, !rb_level(c, i)},
             {&c->rows_expand[i], cand_pair, 4, run_expand_level, true},
-            {i <= MUSICA_CNR_LEVEL ? &c->rows_sdev[i] : nullptr, cand_sdev, 3, run_sdev_level, i <= MUSICA_CNR_LEVEL && env_int("MUSICA_TUNE_SDEV", 1) != 0},
+            {i <= MUSICA_CNR_LEVEL ? &c->rows_sdev[i] : nullptr, cand_sdev, 4, run_sdev_level, i <= MUSICA_CNR_LEVEL && env_int("MUSICA_TUNE_SDEV", 1) != 0},
         };
         for (auto& j : jobs) {
             if (!j.use) continue;
@@ -1108,8 +1126,7 @@ int musica_debug_run_stage(musica_ctx* c, musica_stage stage) {
     c->cur = c->stream;
     switch (stage) {
         case MUSICA_STAGE_NORM:
-            launch_clear(c->stream, c->d_minmax, nullptr, nullptr, nullptr, c->B);
-            enqueue_norm(c);
+            enqueue_norm(c, false);
             break;
         case MUSICA_STAGE_REDUCE: enqueue_reduce(c); break;
         case MUSICA_STAGE_ANALYSIS:

@@ -117,14 +117,8 @@ __device__ __forceinline__ float sum5(float a, float b, float c, float d, float 
     return acc;
 }
 
-// One output row of sdev from its five rows of squares + the histogram scan of that row. y is wave-uniform.
-// alive[j] / start[j]: lane masks (wave-uniform 64-bit values, i.e. scalar registers) — bit l = the run of column c + j of lane l
-// is still counting / starts alive. As per-lane bools the compiler packed them into bytes of two vector registers and spent
-// ~7 vector instructions per texel unpacking, re-arming and repacking them; as lane masks the bookkeeping is two scalar ANDs.
-template <bool HIST, bool A8>
-__device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const SRow& r2, const SRow& r3, const SRow& r4, const SCfg& g, int S,
-                                         int y, int cov, float* __restrict__ drow, const Buf& db, uint32_t row_off, uint32_t* lh,
-                                         unsigned long long (&alive)[8], const unsigned long long (&start)[8]) {
+// The 8 sdev values of a lane for one output row from its five rows of squares (img_sdev.comp:17-30 in MUSICA_ORDER_FAST).
+__device__ __forceinline__ void sdev_values(const SRow& r0, const SRow& r1, const SRow& r2, const SRow& r3, const SRow& r4, const SCfg& g, float (&s)[8]) {
     float q[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) q[j] = sum5(r0.q[j], r1.q[j], r2.q[j], r3.q[j], r4.q[j]);
@@ -135,7 +129,6 @@ __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const S
     if (g.lane0) { a6 = ql0; a7 = ql1; }    // zeros at the image's left edge (loads out of range)
     if (g.lane63) { b0 = qh0; b1 = qh1; }   // zeros beyond the right edge
     // lanes right of the image hold q == 0, so the last in-image lane reads zeros from its neighbour
-    float s[8];
     s[0] = sum5(a6, a7, q[0], q[1], q[2]);
     s[1] = sum5(a7, q[0], q[1], q[2], q[3]);
     s[2] = sum5(q[0], q[1], q[2], q[3], q[4]);
@@ -147,6 +140,9 @@ __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const S
 #pragma unroll
     for (int j = 0; j < 8; j++) s[j] = musica_div25(s[j]);  // img_sdev.comp:30 (exact x / 25, exact_math.h)
     musica_sqrt8(s);                                         // img_sdev.comp:30 (exact sqrt, exact_math.h)
+}
+template <bool A8>
+__device__ __forceinline__ void sdev_store(const float (&s)[8], const SCfg& g, float* __restrict__ drow, const Buf& db, uint32_t row_off) {
     if (A8) {   // whole 16-byte groups, lanes outside the image carry out-of-range offsets: no branch
         bstore4(db, (g.off0 + row_off) | (g.off0 & kOob), make_float4(s[0], s[1], s[2], s[3]));
         bstore4(db, (g.off1 + row_off) | (g.off1 & kOob), make_float4(s[4], s[5], s[6], s[7]));
@@ -158,6 +154,19 @@ __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const S
         for (int j = 0; j < 8; j++)
             if (j < g.valid) drow[g.c + j] = s[j];
     }
+}
+
+// One output row of sdev from its five rows of squares + the histogram scan of that row. y is wave-uniform.
+// alive[j] / start[j]: lane masks (wave-uniform 64-bit values, i.e. scalar registers) — bit l = the run of column c + j of lane l
+// is still counting / starts alive. As per-lane bools the compiler packed them into bytes of two vector registers and spent
+// ~7 vector instructions per texel unpacking, re-arming and repacking them; as lane masks the bookkeeping is two scalar ANDs.
+template <bool HIST, bool A8>
+__device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const SRow& r2, const SRow& r3, const SRow& r4, const SCfg& g, int S,
+                                         int y, int cov, float* __restrict__ drow, const Buf& db, uint32_t row_off, uint32_t* lh,
+                                         unsigned long long (&alive)[8], const unsigned long long (&start)[8]) {
+    float s[8];
+    sdev_values(r0, r1, r2, r3, r4, g, s);
+    sdev_store<A8>(s, g, drow, db, row_off);
     // noise_hist.comp:20-47, branch-free. A run adds until its first `break` (bin 0): alive[j] afterwards is exactly
     // "this texel is counted". A dead column adds into the lane's scratch word; bin 2048 (out of the histogram
     // image, dropped by Q1 without breaking) is a pad word behind the copy (never flushed), so it needs no test of its own. Columns
