@@ -69,8 +69,8 @@ __device__ __forceinline__ void minmax_acc(us2& mn, us2& mx, const uint4& q) {  
 // last block: barrier -> sc1 loads of every slot. The launch also zeroes the image's histograms (the vkCmdClearColorImage
 // calls of src/vk_processing.cpp:2153-2162): every kernel that adds to or reads them runs behind this one.
 constexpr int kMinMaxLoads = 8;
-constexpr int kMinMaxThreads = 1024;
-constexpr int kMinMaxMaxBlocks = 4096;   // slots per image (launch_minmax uses at most 512)
+constexpr int kMinMaxThreads = 256;
+constexpr int kMinMaxMaxBlocks = 4096;   // slots per image (launch_minmax uses at most 256)
 constexpr int kTicketStride = 32;        // words between the tickets of two images: one 128-byte line each (same-line atomics serialise)
 struct ClearArgs {
     uint32_t* noise_hist;    // [batch][4][2048] or null
@@ -707,15 +707,18 @@ void launch_minmax(hipStream_t st, const uint16_t* px, int N, uint32_t* minmax, 
     const size_t count = (size_t)N * N;
     // one trip of kMinMaxLoads loads per lane (2048^2: 64 blocks of 128 KiB) up to 512 blocks per image, then more trips: a block
     // ends with one returning atomic on its image's ticket, ~11 ns apart on one address
-    static const int threads = getenv("MUSICA_MM_THREADS") ? atoi(getenv("MUSICA_MM_THREADS")) : kMinMaxThreads;
-    static const int loads = getenv("MUSICA_MM_LOADS") ? atoi(getenv("MUSICA_MM_LOADS")) : kMinMaxLoads;
-    static const int maxb = getenv("MUSICA_MM_BLOCKS") ? atoi(getenv("MUSICA_MM_BLOCKS")) : 512;
-    size_t blocks = (count / 8 + (size_t)threads * loads - 1) / ((size_t)threads * loads);
+    // 256 blocks per image at most (a block ends with one returning atomic on its image's ticket, ~11 ns apart on one address), 128
+    // with a batch behind them. Measured with rocprofv3 (profiles/r03_minmax_shapes.txt): 8 x 2048^2 21.3 us, one 2048^2 image
+    // 5.8 - 7.3 us, one 8192^2 image 39 - 40 us whatever the shape (256 ... 1024 threads, 4 / 8 loads per lane, 64 ... 2048 blocks per image,
+    // chunks contiguous or a grid-width apart): the launch follows the previous step's gradation apply (268 MB of plain stores
+    // at 8 x 2048^2) and reads while that write backlog drains.
+    const size_t per_block = (size_t)kMinMaxThreads * kMinMaxLoads;
+    size_t blocks = (count / 8 + per_block - 1) / per_block;
+    const size_t maxb = batch >= 4 ? 128 : 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > (size_t)maxb) blocks = maxb;
+    if (blocks > maxb) blocks = maxb;
     ClearArgs ca{noise_hist, grad_hist, grad_hist_b, gzero, clahe_hist};
-    if (loads == 4) hipLaunchKernelGGL(k_minmax_u16<4>, dim3((unsigned)blocks, 1, batch), dim3(threads), 0, st, px, count, minmax, slots, ticket, ca);
-    else hipLaunchKernelGGL(k_minmax_u16<8>, dim3((unsigned)blocks, 1, batch), dim3(threads), 0, st, px, count, minmax, slots, ticket, ca);
+    hipLaunchKernelGGL(k_minmax_u16<kMinMaxLoads>, dim3((unsigned)blocks, 1, batch), dim3(kMinMaxThreads), 0, st, px, count, minmax, slots, ticket, ca);
 }
 
 void launch_normalize(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, const uint32_t* minmax,
