@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 win = float(sys.argv[2]) if len(sys.argv) > 2 else 800.0
 ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']),
              r['Kernel_Name'].split('(')[0].replace('void musica::', '').replace('musica::', ''), r.get('Queue_Id')) for r in rows)
-clears = [k for k in ks if k[2] == 'k_minmax_u16']
+clears = [k for k in ks if k[2].startswith('k_minmax_u16')]
 # the timed steps of the pipeline: the longest run of k_minmax_u16 launches in which consecutive ones sit on different queues
 runs, i = [], 0
 while i < len(clears) - 1:

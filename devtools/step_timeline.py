@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']),
              r['Kernel_Name'].split('(')[0].replace('void musica::', '').replace('musica::', ''), r.get('Queue_Id')) for r in rows)
-clears = [i for i, k in enumerate(ks) if k[2] == 'k_minmax_u16']
+clears = [i for i, k in enumerate(ks) if k[2].startswith('k_minmax_u16')]
 i0, i1 = clears[which], clears[which + 1]
 t0 = ks[i0][0]
 for k in ks[i0:i1]:

@@ -7,7 +7,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void musica::', '').replace('musica::', ''),
              int(r.get('Grid_Size_X', 0) or 0) * int(r.get('Grid_Size_Y', 1) or 1) * int(r.get('Grid_Size_Z', 1) or 1) if 'Grid_Size_X' in r else int(r.get('Grid_Size', 0))) for r in rows)
-clears = [i for i, k in enumerate(ks) if k[2] == 'k_minmax_u16']
+clears = [i for i, k in enumerate(ks) if k[2].startswith('k_minmax_u16')]
 acc = collections.defaultdict(list)
 for a, b in zip(clears[5:-1], clears[6:]):          # skip autotune / warm-up steps
     for k in ks[a:b]:
