@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def per_kernel(path, counter):
-    """{(kernel, grid): [values]} of the pipeline steps (the dispatches after the stand-alone `<1, 2>` launches of
+    """{(kernel, grid): [values]} of the pipeline steps (the dispatches after the stand-alone `k_reduce_dma<2>` launches of
     pmc_target.py; everything before them is musica_create's autotune) and of the stand-alone launches themselves."""
     rows = []
     with open(path, newline="") as f:
@@ -17,7 +17,7 @@ def per_kernel(path, counter):
             if row["Counter_Name"] == counter:
                 rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"], int(row["Grid_Size"]), float(row["Counter_Value"])))
     rows.sort()
-    standalone = ("k_reduce_fast_pf<1, 2", "k_reduce_fast_pf<1, 4", "k_copy41")
+    standalone = ("k_reduce_dma<2>", "k_reduce_dma<4>", "k_copy41")
     last_standalone = max([d for d, n, g, v in rows if any(t in n for t in standalone)] or [0])
     acc = defaultdict(list)
     for d, n, g, v in rows:
@@ -62,11 +62,11 @@ def main():
     for k, v in kernels.items():
         if k.startswith("musica::k_reduce_u16_pf") or "k_reduce_band<true>" in k:   # the level-0 launch of the metric kernel (alone, or fused with the band)
             c4["reduce_l0_hbm_bytes_per_launch"] = v["hbm_bytes_per_launch"]
-        if "k_reduce_fast_pf<1, 2" in k:
+        if "k_reduce_dma<2>" in k:
             res["standalone_4096_warm_hbm_bytes_per_launch"] = v["hbm_bytes_per_launch"]
-        if "k_reduce_fast_pf<1, 4" in k:
+        if "k_reduce_dma<4>" in k:
             res["standalone_4096_cold_hbm_bytes_per_launch"] = v["hbm_bytes_per_launch"]
-        if "k_copy41" in k:
+        if "k_copy41<0>" in k or k.startswith("musica::k_copy41 "):
             res["copy41_4096_cold_hbm_bytes_per_launch"] = v["hbm_bytes_per_launch"]
     res["C4"] = c4
     json.dump(res, open(out, "w"), indent=1)

@@ -1,7 +1,7 @@
 """Target of the rocprofv3 --pmc passes (one dispatch = one counter row, so everything is launched eagerly):
-  1. 16 stand-alone launches of the metric kernel at 4096^2 f32 rotating over 8 distinct buffer pairs (HBM: tag <1, 4>)
+  1. 16 stand-alone launches of the metric kernel at 4096^2 f32 rotating over 8 distinct buffer pairs (HBM: k_reduce_dma<4>)
      and 16 of the copy-shaped ceiling kernel k_copy41 on the same buffers;
-  2. 16 stand-alone launches on one buffer pair (Infinity-Cache resident: tag <1, 2>);
+  2. 16 stand-alone launches on one buffer pair (Infinity-Cache resident: k_reduce_dma<2>);
   3. 3 pipeline steps of workload C4 (8 x 2048^2, 6 levels).
 Usage: rocprofv3 --pmc <counters> --output-format csv -d <dir> -o pmc -- python3 devtools/pmc_target.py"""
 import os

@@ -92,14 +92,6 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void k_reduce_up(const float* _
 // round-robin, wait for their own DMAs, meet at one barrier and then each computes RT/4 output rows from LDS with the
 // register march of the production kernel (rows re-read from LDS, neighbours by DPP, halo columns from a small LDS array
 // filled by two 4-byte DMAs). 2*RT+3 rows of 2 KiB: RT = 16 -> 70 KiB, two workgroups per CU.
-__device__ __forceinline__ void dma16(const Buf& b, uint32_t voff, uint32_t lds_byte) {
-    // M0 = LDS base of this wave-instruction (wave-uniform); the 64 lanes land at M0 + 16 * lane
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_byte), "v"(voff), "s"(b.r) : "memory", "m0");
-}
-__device__ __forceinline__ void dma4(const Buf& b, uint32_t voff, uint32_t lds_byte) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_byte), "v"(voff), "s"(b.r) : "memory", "m0");
-}
-
 __device__ __forceinline__ void dma16nt(const Buf& b, uint32_t voff, uint32_t lds_byte) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" ::"s"(lds_byte), "v"(voff), "s"(b.r) : "memory", "m0");
 }
@@ -145,7 +137,7 @@ __global__ __launch_bounds__(64 * W) void k_reduce_lds(const float* __restrict__
             const int y = min(max(mirror_idx(2 * yo0 - 2 + k, hi), 0), hi);
             const uint32_t col_off = lane_off + (uint32_t)half * 1024u;
             const bool ok = c0 + half * 256 + lane * 4 < S;
-            if (NTL) dma16nt(ib, ok ? (uint32_t)y * rb + col_off : kOob, lds0 + (uint32_t)(k * kStripCols + half * 256) * 4u);
+            if (NTL == 1 || (NTL == 2 && k >= 3 && k < 2 * RT)) dma16nt(ib, ok ? (uint32_t)y * rb + col_off : kOob, lds0 + (uint32_t)(k * kStripCols + half * 256) * 4u);   // NTL == 2: only the rows no other tile reads
             else dma16(ib, ok ? (uint32_t)y * rb + col_off : kOob, lds0 + (uint32_t)(k * kStripCols + half * 256) * 4u);
         }
     }
@@ -267,7 +259,7 @@ static void l_lds(hipStream_t st, const float* in, float* out, int S) {
 template <int RPW>
 static void l_prod(hipStream_t st, const float* in, float* out, int S) {
     LevelDesc li{S, S, (size_t)S * S}, lo{S / 2, S / 2, (size_t)(S / 2) * (S / 2)};
-    launch_reduce(st, in, li, out, lo, 1, RPW, false, 4);
+    launch_reduce(st, in, li, out, lo, 1, false, 4);   // the production kernel (k_reduce_dma); RPW is unused since round 3
 }
 static void l_copy41(hipStream_t st, const float* in, float* out, int S) { launch_copy41(st, in, out, S); }
 static void l_copy41nt(hipStream_t st, const float* in, float* out, int S) {
@@ -285,12 +277,10 @@ int main(int argc, char** argv) {
     const int NBUF = S >= 8192 ? 3 : 8;
     const int iters = S >= 8192 ? 24 : 64;
     std::vector<Variant> vars = {
-        {"prod_rpw4", l_prod<4>}, {"prod_rpw8", l_prod<8>},
+        {"prod", l_prod<4>},
         {"up_r4", l_up<4, 4, 0>}, {"up_r4_nts", l_up<4, 4, 1>}, {"up_r4_ntl", l_up<4, 4, 2>}, {"up_r6", l_up<6, 3, 0>}, {"up_r8", l_up<8, 2, 0>}, {"up_r2", l_up<2, 4, 0>}, {"up_r3", l_up<3, 4, 0>},
-        {"lds_rt4_nts", l_lds<4, 4, 2, 0, 0, 0>}, {"lds_rt8_nts", l_lds<8, 4, 2, 0, 0, 0>}, {"lds_rt16_w8", l_lds<16, 8, 2, 0, 0, 0>},
-        {"lds_rt4_sc1", l_lds<4, 4, 16, 0, 0, 0>}, {"lds_rt4_sc01", l_lds<4, 4, 17, 0, 0, 0>}, {"lds_rt4_sc0nt", l_lds<4, 4, 3, 0, 0, 0>}, {"lds_rt4_ntsc1", l_lds<4, 4, 18, 0, 0, 0>}, {"lds_rt4_sc0", l_lds<4, 4, 1, 0, 0, 0>},
-        {"lds_rt4_swz", l_lds<4, 4, 2, 0, 0, 1>}, {"lds_rt6_w2", l_lds<6, 2, 2, 0, 0, 0>}, {"lds_rt6_w3", l_lds<6, 3, 2, 0, 0, 0>}, {"lds_rt6_w6", l_lds<6, 6, 2, 0, 0, 0>},
-        {"lds_rt2_w2", l_lds<2, 2, 2, 0, 0, 0>}, {"lds_rt3_w3", l_lds<3, 3, 2, 0, 0, 0>}, {"lds_rt5_w5", l_lds<5, 5, 2, 0, 0, 0>}, {"lds_rt8_w8", l_lds<8, 8, 2, 0, 0, 0>},
+        {"lds_rt4_nts", l_lds<4, 4, 2, 0, 0, 0>}, {"lds_rt4_nts_ntli", l_lds<4, 4, 2, 2, 0, 0>}, {"lds_rt8_nts", l_lds<8, 4, 2, 0, 0, 0>}, {"lds_rt8_nts_ntli", l_lds<8, 4, 2, 2, 0, 0>},
+        {"lds_rt8_w8", l_lds<8, 8, 2, 0, 0, 0>}, {"lds_rt8_w8_ntli", l_lds<8, 8, 2, 2, 0, 0>}, {"lds_rt6_w3", l_lds<6, 3, 2, 0, 0, 0>}, {"lds_rt6_w3_ntli", l_lds<6, 3, 2, 2, 0, 0>},
         {"copy41", l_copy41}, {"copy41x2", l_copy41x2}, {"copy41_nts", l_copy41nt},
     };
     const size_t ip = (size_t)S * S, op = (size_t)So * So;

@@ -15,6 +15,8 @@ namespace musica {
 
 // One thread per output float4: the 2 x 2 float4 block of input above it (two rows, 32 contiguous bytes each),
 // i.e. a 256-thread block reads 2 x 8 KiB of two consecutive input rows and writes 4 KiB of one output row.
+// TAG: 0 = sides <= 4096, 1 = above (keeps bench.py's two sizes apart in a profiler's per-symbol averages)
+template <int TAG>
 __global__ __launch_bounds__(256) void k_copy41(const float4* __restrict__ in, float4* __restrict__ out, int S4 /* float4 per input row */, int So4) {
     const int xo = blockIdx.x * blockDim.x + threadIdx.x;
     const int yo = blockIdx.y;
@@ -29,7 +31,8 @@ __global__ __launch_bounds__(256) void k_copy41(const float4* __restrict__ in, f
 
 void launch_copy41(hipStream_t st, const float* in, float* out, int side) {
     const int So = side / 2, So4 = So / 4;
-    hipLaunchKernelGGL(k_copy41, dim3((So4 + 255) / 256, So), dim3(256), 0, st, reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out),
+    auto* kern = side <= 4096 ? k_copy41<0> : k_copy41<1>;
+    hipLaunchKernelGGL(kern, dim3((So4 + 255) / 256, So), dim3(256), 0, st, reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out),
                        side / 4, So4);
 }
 

@@ -128,15 +128,17 @@ __device__ __forceinline__ void reduce_row(const RowR& r0, const RowR& r1, const
 // wavefront computes one output row: five 16-byte-pair LDS reads per lane, the vertical 5-tap pass in registers, the
 // horizontal pass with its 2 + 1 neighbour columns from the adjacent lanes by DPP wave shifts (halo columns on lane 0 /
 // 63), one non-temporal 16-byte store per lane (the output is not read again by this launch: a plain store leaves the
-// lines dirty in the XCD's L2 and their write-back competes with the incoming rows — 18.7 -> 15.9 us at 4096^2).
+// lines dirty in the XCD's L2 and their write-back competes with the incoming rows — 18.7 -> 15.9 us at 4096^2). The five rows
+// of a tile that no other tile reads come in with the non-temporal policy (15.9 -> 14.85 us, see the loop).
 // 22 KiB of LDS per workgroup: 7 workgroups = 154 KiB of rows in flight per CU, and the grid is fine-grained enough
 // (4096 workgroups at 4096^2) that the tail of the launch is short. Measured from HBM on MI355X (DESIGN.md §6,
-// profiles/r03_*): 4096^2 15.9 us = 0.66 of 8 TB/s (register-staged march of rounds 1-2: 19.3; a plain copy of the same
-// traffic shape: 16.0, with non-temporal stores 15.4), 8192^2 55.3 us = 0.76 (march 65.6, copy 59.3).
+// profiles/r03_*): 4096^2 14.85 us = 0.706 of 8 TB/s (register-staged march of rounds 1-2: 19.3; a plain copy of the same
+// traffic shape: 16.1, with non-temporal stores 15.4), 8192^2 51.6 us = 0.81 (march 65.6, copy 58.7).
 // Rows the mirror sends outside [0, S) (only when S < 3 could that happen; the fast path needs S >= 8) do not occur; the
 // last tile of an image whose So is not a multiple of kDmaRows re-requests valid rows and drops the surplus output rows.
 // TAG only separates the launch sites in profiler output: 0 / 1 = level 0 / levels >= 1 of a pipeline that does not fuse
-// reduce + band, 2 = stand-alone musica_k_reduce, 4 = stand-alone rotating over distinct planes (musica_k_reduce_timed_rot).
+// reduce + band, 2 = stand-alone musica_k_reduce, 4 / 5 = stand-alone rotating over distinct planes at sides <= 4096 / above
+// (musica_k_reduce_timed_rot: bench.py's 4096^2 and 8192^2 measurements stay apart in a profiler's per-symbol averages).
 constexpr int kDmaRows = 4;                           // output rows per workgroup (one per wavefront)
 constexpr int kDmaInRows = 2 * kDmaRows + 3;          // input rows of a tile
 constexpr int kDmaPieces = 2 * kDmaInRows;            // 1 KiB pieces (half rows)
@@ -149,6 +151,12 @@ static_assert(kDmaRows == kWavesPerBlock && kDmaInRows * 3 <= 64, "tile shape");
 __device__ __forceinline__ void dma16(const Buf& b, uint32_t voff, uint32_t lds_byte) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(b.r) : "memory");
+}
+// the same with the non-temporal cache policy: for bytes no other workgroup will ask for
+__device__ __forceinline__ void dma16_nt(const Buf& b, uint32_t voff, uint32_t lds_byte) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen nt lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(b.r) : "memory");
 }
 __device__ __forceinline__ void dma4(const Buf& b, uint32_t voff, uint32_t lds_byte) {
@@ -189,7 +197,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_dma(const float* __res
         const int k = q >> 1, half = q & 1;
         const int y = min(max(mirror_idx(2 * yo0 - 2 + k, hi), 0), hi);
         const bool ok = c0 + half * 256 + lane * 4 < S;
-        dma16(ib, ok ? (uint32_t)y * rb + lane_off + (uint32_t)half * 1024u : kOob, lds0 + (uint32_t)(k * kStripCols + half * 256) * 4u);
+        const uint32_t src = ok ? (uint32_t)y * rb + lane_off + (uint32_t)half * 1024u : kOob, dst = lds0 + (uint32_t)(k * kStripCols + half * 256) * 4u;
+        // rows 0-2 and 8-10 of a tile are also the tile above's / below's: default policy, so the second reader finds them in the
+        // XCD's L2; rows 3-7 are read by nobody else: non-temporal, they do not push the shared rows out (a CU's seven tiles x 32 CUs
+        // are 4.9 MB in flight against 4 MiB of L2). 4096^2: 15.9 -> 14.85 us, 8192^2: 55.3 -> 51.6 us; nt on every row: 17.9 us.
+        if (k >= 3 && k < 2 * kDmaRows) dma16_nt(ib, src, dst);   // wave-uniform
+        else dma16(ib, src, dst);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1057,7 +1070,7 @@ void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* 
         // 8 k strips: workgroup id % 8 == strip % 8 already gives every strip one XCD, tile above tile in dispatch order; otherwise
         // the XCD-aware mapping does (2048^2: 6.0 -> 5.05 us; it costs 1.5 us at 4096^2 where the plain mapping has that property)
         const int swz = (strips % 8) != 0 ? xcd_swizzle_on() : 0;
-        auto* kern = tag == 0 ? k_reduce_dma<0> : tag == 1 ? k_reduce_dma<1> : tag == 2 ? k_reduce_dma<2> : k_reduce_dma<4>;
+        auto* kern = tag == 0 ? k_reduce_dma<0> : tag == 1 ? k_reduce_dma<1> : tag == 2 ? k_reduce_dma<2> : tag == 4 ? k_reduce_dma<4> : k_reduce_dma<5>;
         hipLaunchKernelGGL(kern, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, swz);
     } else {
         hipLaunchKernelGGL(k_reduce_generic, generic_grid(lo.S, batch), kGenericBlock, 0, st, in, out, li.S, li.pitch,
@@ -1116,12 +1129,9 @@ static void launch_expand_t(hipStream_t st, const ExpandArgs& a, int batch, bool
         const dim3 grid = stream_grid(a.S, a.Sc, a.rows_per_wave, batch);
         if (GAIN == GAIN_CURVE && NR && a.ghist) {   // level 0 with the gradation histogram on board (the caller checked cnrScale == 8)
             // W = 4: register allocation capped at 128 (4 wavefronts per SIMD, 16 dwords of scratch) against 143 registers and 3 wavefronts
-            static const int occ = getenv("MUSICA_GH_OCC") ? atoi(getenv("MUSICA_GH_OCC")) : 4;
-            if (a.le090 && rows_per_trip < 2 && occ >= 4) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 4, true>), grid, dim3(kBlockThreads), 0, st, a);
-            else if (a.le090) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 1, true>), grid, dim3(kBlockThreads), 0, st, a);
+            if (a.le090) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 4, true>), grid, dim3(kBlockThreads), 0, st, a);
             else if (rows_per_trip >= 2) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 2, true>), grid, dim3(kBlockThreads), 0, st, a);
-            else if (occ >= 4) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 4>), grid, dim3(kBlockThreads), 0, st, a);
-            else hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 1>), grid, dim3(kBlockThreads), 0, st, a);
+            else hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 4>), grid, dim3(kBlockThreads), 0, st, a);
         }
         else if (rows_per_trip >= 2) hipLaunchKernelGGL((k_expand_fast<GAIN, NR, 2, false>), grid, dim3(kBlockThreads), 0, st, a);
         else hipLaunchKernelGGL((k_expand_fast<GAIN, NR, 1, false, NR ? 4 : 1>), grid, dim3(kBlockThreads), 0, st, a);   // NR: 129 registers wanted, capped at 128 (4 wavefronts per SIMD)

@@ -421,14 +421,13 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->reduce_rows = env_int("MUSICA_REDUCE_ROWS", 16);
     c->band_trip = env_int("MUSICA_BAND_TRIP", 2);
     c->expand_trip = env_int("MUSICA_EXPAND_TRIP", 1);
-    c->min_waves = env_int("MUSICA_MIN_WAVES", 2048);
+    c->min_waves = 2048;
     c->band_rows = env_int("MUSICA_BAND_ROWS", 8);
     c->expand_rows = env_int("MUSICA_EXPAND_ROWS", 8);
     c->sdev_rows = env_int("MUSICA_SDEV_ROWS", 32) & ~15;
     if (c->sdev_rows < 16) c->sdev_rows = 16;
     g_min_waves = c->min_waves;
-    c->grad_groups = env_int("MUSICA_GRAD_GROUPS", 1);
-    if (c->grad_groups < 1) c->grad_groups = 1;
+    c->grad_groups = 1;
 
     const size_t B = (size_t)c->B;
     // 1: the three-stream form (enqueue_dag), the fastest for a context that has the GPU to itself (one 2048^2 image 0.204 vs
@@ -972,7 +971,7 @@ static void autotune(musica_ctx* c) {
             {&c->rows_reduce[i], cand_reduce, 5, run_reduce_level, !rb_level(c, i) && i == 0 && c->fuse_u16},
             {&c->rows_band[i], cand_pair, 4, run_band_level, !rb_level(c, i)},
             {&c->rows_expand[i], cand_pair, 4, run_expand_level, true},
-            {i <= MUSICA_CNR_LEVEL ? &c->rows_sdev[i] : nullptr, cand_sdev, 4, run_sdev_level, i <= MUSICA_CNR_LEVEL && env_int("MUSICA_TUNE_SDEV", 1) != 0},
+            {i <= MUSICA_CNR_LEVEL ? &c->rows_sdev[i] : nullptr, cand_sdev, 4, run_sdev_level, i <= MUSICA_CNR_LEVEL},
         };
         for (auto& j : jobs) {
             if (!j.use) continue;
@@ -1563,7 +1562,7 @@ int musica_k_reduce_timed_rot(musica_ctx* c, const float* d_in, uint32_t side, u
     HIP_OK(hipEventCreate(&b));
     HIP_OK(hipEventRecord(a, c->stream));
     for (uint32_t i = 0; i < iters; i++)
-        launch_reduce(c->stream, d_in + (size_t)(i % nbuf) * li.plane, li, d_out + (size_t)(i % nbuf) * lo.plane, lo, 1, c->generic, 4);
+        launch_reduce(c->stream, d_in + (size_t)(i % nbuf) * li.plane, li, d_out + (size_t)(i % nbuf) * lo.plane, lo, 1, c->generic, side <= 4096 ? 4 : 5);
     HIP_OK(hipEventRecord(b, c->stream));
     HIP_OK(hipEventSynchronize(b));
     float ms = 0.f;

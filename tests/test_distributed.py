@@ -170,3 +170,19 @@ def test_bench_rank_mismatch_is_refused_without_a_gpu():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=120, cwd=root)
     assert r.returncode != 0 and "WORLD_SIZE (2) != --gpus (8)" in r.stderr
+
+
+def test_self_launcher_relays_a_failing_rank_as_a_failure():
+    """`bench.py --gpus 2` started plainly becomes the launcher of its two ranks. A rank that exits non-zero — here every rank:
+    this container has no HIP device, so each stops with 'needs a HIP device' (or, on a one-GPU box, rank 1 finds no cuda:1) — must
+    make the launcher itself exit non-zero and print no result line: a partial job is never reported as a smaller one."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MUSICA_BENCH_ONE_DEVICE")}
+    env["HIP_VISIBLE_DEVICES"] = ""          # also on a GPU box: the ranks see no device
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode != 0
+    assert '"metric"' not in r.stdout
+    assert "rank launcher exited with code" in (r.stderr + r.stdout)

@@ -185,11 +185,12 @@ def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
             p.cleanup()
 
 
-@pytest.mark.parametrize("env", [{"MUSICA_BAND_TRIP": "1"}, {"MUSICA_EXPAND_TRIP": "2"}, {"MUSICA_U16": "0"}, {"MUSICA_FUSE_GH": "0"}, {"MUSICA_GH_OCC": "3"}, {"MUSICA_FUSE_RB": "0"}, {"MUSICA_FUSE_RB": "1"}, {"MUSICA_LE090": "0"}, {"MUSICA_GH_OCC": "3", "MUSICA_LE090": "1"}, {"MUSICA_XCD_SWIZZLE": "0"},
+@pytest.mark.parametrize("env", [{"MUSICA_BAND_TRIP": "1"}, {"MUSICA_EXPAND_TRIP": "2"}, {"MUSICA_U16": "0"}, {"MUSICA_FUSE_GH": "0"}, {"MUSICA_FUSE_RB": "0"}, {"MUSICA_FUSE_RB": "1"}, {"MUSICA_LE090": "0"}, {"MUSICA_XCD_SWIZZLE": "0"},
+                                 {"MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "0"}, {"MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "1"},
                                  {"MUSICA_FUSE_RB": "2", "MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "4"}, {"MUSICA_FUSE_RB": "2", "MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "64"},
                                  {"MUSICA_FUSE_GH": "1", "MUSICA_EXPAND_TRIP": "2"},
                                  {"MUSICA_AUTOTUNE": "0", "MUSICA_REDUCE_ROWS": "4", "MUSICA_BAND_ROWS": "2", "MUSICA_EXPAND_ROWS": "2", "MUSICA_SDEV_ROWS": "16"},
-                                 {"MUSICA_AUTOTUNE": "0", "MUSICA_REDUCE_ROWS": "32", "MUSICA_BAND_ROWS": "16", "MUSICA_EXPAND_ROWS": "16", "MUSICA_SDEV_ROWS": "64", "MUSICA_MIN_WAVES": "1"}],
+                                 {"MUSICA_AUTOTUNE": "0", "MUSICA_REDUCE_ROWS": "32", "MUSICA_BAND_ROWS": "16", "MUSICA_EXPAND_ROWS": "16", "MUSICA_SDEV_ROWS": "64", "MUSICA_SDEV_RUN": "0"}],
                          ids=lambda e: ",".join("%s=%s" % (k[7:], v) for k, v in e.items()))
 def test_kernel_variants_and_launch_geometries_give_the_same_bits(ob, env, monkeypatch):
     """The alternative forms of the streaming kernels kept in the library (rows-per-trip of band / expand, stored
