@@ -22,15 +22,18 @@ the ranks do not all join; under an external launcher (WORLD_SIZE set) it is one
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = megapixels/s of the whole job, plus
   roofline            : the metric kernel BASELINE.json names — fused 5-tap smooth + 2x downsample
-                        (k_reduce_fast_pf) on 4096 x 4096 f32 — timed with HIP events on the library's stream
+                        (k_reduce_dma) on 4096 x 4096 f32 — timed with HIP events on the library's stream
                         over back-to-back launches that ROTATE over 8 distinct input / output planes (640 MB,
                         so no launch finds its data in the 256 MiB Infinity Cache): an HBM number;
                         copy_ceiling = a plain streaming kernel of the same traffic shape timed the same way;
+                        at_8192 = the same measurement at 8192 x 8192 (3 plane pairs, 1 GB);
   roofline_4096_warm  : the same launches on ONE input plane (cache-resident: 80 MB inside the Infinity Cache);
   roofline_pipeline_l0: the level-0 launch of that kernel inside the pipeline (raw uint16 input normalised on
                         the fly, 3 B/px), HIP events around it in a pass over the same K steps;
   kernels             : per-kernel-family mean duration, algorithmic GB/s and share of the step;
-  cpu_baseline        : the CPU oracle (a port: the reference has no CPU path) on a bounded sample.
+  cpu_baseline        : the CPU oracle (a port: the reference has no CPU path) on a bounded sample;
+  reference_3072_L12  : one 3072 x 3072 image per execute with the reference's 12 levels, one context (the reference's call shape);
+  cli                 : wall time of `musica-standalone image.raw out.bmp` at that size, 5 fresh processes, and its own timing line.
 """
 import argparse
 import json
@@ -522,6 +525,9 @@ def main():
             "metric": "megapixels/sec full MUSICA pipeline", "value": round(mpix / elapsed, 1), "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_is": "whole-job MP/s of %d steps enqueued round-robin on %d one-stream contexts of each GPU (steps in flight), every context replaying its own HBM-resident copy "
+                        "of the rank's %d-image shard (inputs do not change between steps; H2D excluded); `one_context`, `single_image`, `reference_3072_L12`, `e2e_host_*` "
+                        "and `cli` are the same pipeline in the reference's one-frame-at-a-time call shapes" % (args.steps, depth, batch),
             "config": {"workload": desc, "image_size": n, "levels": levels, "images_per_gpu_per_step": batch, "contexts_in_flight": depth, "untimed_rehearsals_of_the_job": rehearsals,
                        "queue_calibration_ms": queue_calibration,
                        "input": "seeded phantoms, %d-bit" % bits, "dispatch": "eager launches" if (kernel_events or os.environ.get("MUSICA_GRAPH", "1") == "0") else "hipGraph replay",

@@ -208,10 +208,14 @@ static int pick_rows(int dflt, int min_rows, int S, int rows_total, int batch, i
     return rpw < min_rows ? min_rows : rpw;
 }
 // Rows per wavefront of the sdev + noise-histogram launch of level i; 0 = one 16-row run per workgroup (k_sdev_hist_run), the
-// form for every launch that cannot fill the chip with 16-row marches (levels >= 1; MUSICA_SDEV_RUN=0 / 1: never / always).
+// form for every launch that cannot fill the chip with 16-row marches (MUSICA_SDEV_RUN=0 / 1: never / always).
 static int sdev_rows_default(const musica_ctx* c, int i, int batch) {
     const int mode = env_int("MUSICA_SDEV_RUN", -1);
-    if (mode == 1 || (mode < 0 && i >= 1)) return 0;
+    // 16-row marches of this launch: with fewer than one per SIMD (1024) each walks its 20 dependent row trips alone (17 - 18 us
+    // whatever the size); the run form costs 9 - 13 us there but reads its input twice: slower once the marches fill the chip
+    // (8 x 2048^2, every kernel alone: level 0 74.7 against 61.5 us, level 1 27.4 / 23.6, level 2 13.1 / 18.8, level 3 9.9 / 18.1)
+    const long marches = (long)((c->lv[i].S + kStripCols - 1) / kStripCols) * ((c->lv[i].S + kHistArea - 1) / kHistArea) * batch;
+    if (mode == 1 || (mode < 0 && marches < 1024)) return 0;
     return pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, batch);
 }
 
@@ -435,7 +439,8 @@ static musica_ctx* create_impl(const musica_params* params) {
     // order — the form for contexts whose steps run beside other contexts' steps (batch.ShardPipeline): such a context
     // creates ONE stream, so that the runtime's round-robin puts consecutive contexts on different hardware queues
     // (4 by default), and nothing of a step ever waits for an event of another queue. Both forms replay a captured hipGraph.
-    c->dag = (params->flags & MUSICA_FLAG_LINEAR) ? 0 : env_int("MUSICA_DAG", 1);
+    // (a pyramid with a long tail of tiny levels — the reference's own 3072^2 / L = 12 — is faster on one stream: 0.297 against 0.318 ms)
+    c->dag = (params->flags & MUSICA_FLAG_LINEAR) ? 0 : env_int("MUSICA_DAG", L >= 11 ? 0 : 1);
     if (c->dag < 0 || c->dag > 1) c->dag = 1;
     c->use_graph = !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", 1) != 0;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
