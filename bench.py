@@ -117,6 +117,7 @@ def parse_args():
     ap.add_argument("--no-single-image", action="store_true", help="skip the one-image-per-execute measurement (keeps a kernel trace of the run pure)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel event passes after the timed region")
     ap.add_argument("--no-standalone", action="store_true", help="skip the stand-alone 4096^2 metric-kernel measurements (roofline becomes the in-pipeline launch)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect the metric kernel's HBM traffic with rocprofv3 --pmc (roofline.traffic then comes from profiles/pmc_traffic.json)")
     ap.add_argument("--no-cli", action="store_true", help="skip the drop-in measurement (musica-standalone <raw> <bmp> in fresh processes at 3072^2 / L12)")
     return ap.parse_args()
 
@@ -144,6 +145,46 @@ def self_launch(args):
     if got.get("n_gpus") != args.gpus:
         raise SystemExit("bench.py --gpus %d: the result line reports n_gpus = %r" % (args.gpus, got.get("n_gpus")))
     print(line)
+
+
+def measure_metric_traffic(timeout=150):
+    """HBM-side bytes per launch of the stand-alone metric kernel at 4096^2 from HBM, collected NOW: two rocprofv3 passes
+    (FETCH_SIZE and WRITE_SIZE cannot share a pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots') of devtools/pmc_metric_target.py as child
+    processes, --pmc with no trace option. Units and corrections as that guide prescribes for gfx950: both counters are KiB; FETCH_SIZE
+    tallies wide streaming reads at half their size (x 2); WRITE_SIZE is exact. Returns (bytes, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    target = os.path.join(ROOT, "devtools", "pmc_metric_target.py")
+    got = {}
+    td = tempfile.mkdtemp(prefix="musica_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(td, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable, target]
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=td, env=dict(os.environ, TMPDIR=td))
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s timed out" % counter
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (exit %d)" % (counter, r.returncode)
+            rows = []
+            for row in csv.DictReader(open(files[0], newline="")):
+                if row["Counter_Name"] == counter and "k_reduce_dma<4>" in row["Kernel_Name"]:
+                    rows.append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+            rows.sort()
+            vals = [v for _, v in rows][-16:]          # the 16 counted launches (the first rotation is the warm-up)
+            if len(vals) < 16:
+                return None, "only %d k_reduce_dma<4> dispatches in the %s pass" % (len(vals), counter)
+            got[counter] = sum(vals) / len(vals)
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    fetch, write = 2.0 * 1024.0 * got["FETCH_SIZE"], 1024.0 * got["WRITE_SIZE"]
+    return int(round(fetch + write)), {"fetch_bytes": int(round(fetch)), "write_bytes": int(round(write)), "launches_averaged": 16}
 
 
 def cpu_model():
@@ -381,6 +422,8 @@ def main():
                         "bound": "hbm", "achieved": gb(cold_us), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb(cold_us) / HBM_PEAK_GBS, 4),
                         "traffic": traffic_doc.get("standalone_4096_cold_hbm_bytes_per_launch"), "traffic_source": traffic_source,
                         "algorithmic_bytes_per_launch": b4096, "mean_us": round(cold_us, 2),
+                        "traffic_note": "FETCH_SIZE x 2 as the guide prescribes for 16-byte streaming reads; the excess over the algorithmic bytes is the same for every tile height "
+                                        "(not row re-reads): the 4-byte halo-column gathers of the tiles, a width the guide marks as uncalibrated for the x 2 (DESIGN.md section 4)",
                         "measured": "one HIP event pair around the %d launches on the library's stream, right after the timed steps" % COLD_ITERS,
                         "copy_ceiling": {"kernel": "k_copy41: plain streaming kernel, same traffic shape (read S^2 f32, write (S/2)^2 f32), same rotation",
                                          "achieved": gb(copy_us), "unit": "GB/s", "mean_us": round(copy_us, 2),
@@ -391,6 +434,15 @@ def main():
             roofline["at_8192"] = {"achieved": round(b8192 / (cold8_us * 1e-6) / 1e9, 1), "unit": "GB/s", "frac": round(b8192 / (cold8_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                    "mean_us": round(cold8_us, 2), "algorithmic_bytes_per_launch": b8192,
                                    "copy_ceiling_us": round(copy8_us, 2), "measured": "24 back-to-back launches rotating over 3 distinct 8192x8192 plane pairs (1 GB)"}
+            if world == 1 and not args.no_pmc:
+                tb, detail = measure_metric_traffic()
+                if tb is not None:
+                    roofline["traffic"] = tb
+                    roofline["traffic_source"] = ("measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no trace option) of devtools/pmc_metric_target.py "
+                                                  "as child processes; KiB -> bytes, FETCH_SIZE x 2, WRITE_SIZE exact (MI355X_MICROARCH.md); mean of 16 launches of k_reduce_dma<4>")
+                    roofline["traffic_detail"] = detail
+                else:
+                    roofline["traffic_source"] = traffic_source + " [live collection unavailable: %s]" % detail
             warm = {"kernel": "the same kernel, 200 back-to-back launches on ONE 4096x4096 input (80 MB: cache-resident in the 256 MiB Infinity Cache, not an HBM number)",
                     "bound": "infinity-cache", "achieved": gb(warm_us), "unit": "GB/s", "frac_of_hbm_peak": round(gb(warm_us) / HBM_PEAK_GBS, 4),
                     "mean_us": round(warm_us, 2), "algorithmic_bytes_per_launch": b4096}
