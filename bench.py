@@ -402,7 +402,7 @@ def main():
             k = kernels["reduce_l0"]
             pipeline_l0 = {"kernel": "%s (5-tap smooth + 2x downsample, level 0 of the pipeline, %d images of %dx%d per launch; input read as %s)"
                                      % ("k_reduce_band_u16 — smooth + downsample AND the band-pass image in one march" if proc.fuses_reduce_band() else
-                                        "k_reduce_u16_pf" if fused else "k_reduce_fast_pf", batch, n, n,
+                                        "k_reduce_u16_pf" if fused else "k_reduce_dma", batch, n, n,
                                         "raw uint16 normalised on the fly: 2 B/px in + 1 B/px (+ 4 B/px band) out" if fused else "f32: 4 B/px in + 1 B/px out"),
                            "bound": "hbm", "achieved": k["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(k["alg_GBps"] / HBM_PEAK_GBS, 4),

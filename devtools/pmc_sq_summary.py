@@ -20,7 +20,7 @@ def main():
             for r in csv.DictReader(f):
                 rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"]),
                              int(r["VGPR_Count"]), int(r["SGPR_Count"]), int(r["LDS_Block_Size"])))
-        standalone = ("k_reduce_fast_pf<1, 2", "k_reduce_fast_pf<1, 4", "k_copy41")
+        standalone = ("k_reduce_dma<2>", "k_reduce_dma<4>", "k_copy41")
         last = max([d for d, n, *_ in rows if any(t in n for t in standalone)] or [0])
         for d, n, g, cn, v, vg, sg, lds in rows:
             if "musica" not in n:

@@ -1,6 +1,7 @@
 // kernels_analysis.hip — normalisation and image-analysis kernels of the MUSICA path (gfx950).
 //
-//   k_clear         : vkCmdClearColorImage of the histograms (src/vk_processing.cpp:2153-2162) + reduction seeds
+//   k_clear         : vkCmdClearColorImage of the histograms (src/vk_processing.cpp:2153-2162) for the single-stage debug entry points
+//                     (on the hot path the clears ride in k_minmax_u16)
 //   k_minmax_u16    : img_sqrt.comp + img_max_reduce.comp chain + min_reduce.comp chain   (K1 + K2 + K3)
 //   k_normalize     : img_sqrt.comp + img_normalize.comp                                    (K1 + K4)
 //   k_sdev_hist     : img_sdev.comp + noise_hist.comp fused                                 (K10 + K11)

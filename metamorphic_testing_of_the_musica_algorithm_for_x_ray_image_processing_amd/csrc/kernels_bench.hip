@@ -3,7 +3,7 @@
 //   k_copy41 : a plain streaming kernel with the traffic shape of the metric kernel (img_smooth.comp +
 //              img_downsample.comp fused: read S^2 f32 once, write (S/2)^2 f32 once) and nothing else —
 //              no halo rows, no halo columns, three adds per loaded float4. bench.py times it beside
-//              k_reduce_fast_pf, the same rotating-buffer way, so that the metric kernel's fraction of the
+//              k_reduce_dma, the same rotating-buffer way, so that the metric kernel's fraction of the
 //              8 TB/s HBM peak can also be read against what a streaming kernel of this shape attains on
 //              the same box (musica_k_copy41_timed_rot, include/musica.h). A grid-stride form (2048 / 4096 workgroups streaming
 //              4 contiguous 16-byte loads per trip) measured the same 16.0 us at 4096^2 from HBM, non-temporal loads 22 us.

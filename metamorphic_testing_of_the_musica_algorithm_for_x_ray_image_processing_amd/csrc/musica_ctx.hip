@@ -436,7 +436,7 @@ static musica_ctx* create_impl(const musica_params* params) {
     const size_t B = (size_t)c->B;
     // 1: the three-stream form (enqueue_dag), the fastest for a context that has the GPU to itself (one 2048^2 image 0.204 vs
     // 0.215 ms, 8 x 2048^2 0.484 vs 0.496 ms); 0 (MUSICA_FLAG_LINEAR, or MUSICA_DAG=0): one in-order stream in the reference's
-    // order — the form for contexts whose steps run beside other contexts' steps (batch.ShardPipeline): such a context
+    // order — the form for contexts whose steps run beside other contexts' steps (musica_pipeline_*): such a context
     // creates ONE stream, so that the runtime's round-robin puts consecutive contexts on different hardware queues
     // (4 by default), and nothing of a step ever waits for an event of another queue. Both forms replay a captured hipGraph.
     // (a pyramid with a long tail of tiny levels — the reference's own 3072^2 / L = 12 — is faster on one stream: 0.297 against 0.318 ms)
@@ -1631,7 +1631,7 @@ int musica_memcpy_d2h(musica_ctx* c, void* dst, const void* d_src, size_t bytes)
 // of an MI355X do not run side by side, so one context per queue is created and musica_pipeline_prime() times every cyclic
 // window of `depth` of them for a few steps, keeps the fastest and destroys the rest (three contexts: 0.36 ms per 8 x 2048^2
 // step on a good window, 0.41 on a bad one). The reference has one VulkanProcessing and one frame in flight
-// (src/vk_processing.cpp:2535-2536); this is the throughput form of it, for C / C++ callers what batch.ShardPipeline is in Python.
+// (src/vk_processing.cpp:2535-2536); this is the throughput form of it.
 struct musica_pipeline {
     std::vector<musica_ctx*> ctx;   // before prime(): one per hardware queue; after: the `depth` that stay, in step order
     uint32_t depth;
