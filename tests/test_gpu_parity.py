@@ -416,7 +416,7 @@ def test_streaming_kernels_equal_generic_kernels(n, levels):
     b.cleanup()
 
 
-@pytest.mark.parametrize("side", [8, 16, 24, 64, 100, 257, 512, 520, 1024, 1032, 3, 2, 1, 5, 7, 12])
+@pytest.mark.parametrize("side", [8, 16, 24, 64, 100, 257, 512, 520, 1024, 1032, 2048, 3080, 3, 2, 1, 5, 7, 12])
 def test_metric_kernel_vs_oracle(ob, side):
     rng = np.random.default_rng(side)
     img = rng.random((2, side, side), dtype=np.float32)
@@ -430,16 +430,16 @@ def test_metric_kernel_vs_oracle(ob, side):
     p.cleanup()
 
 
-def test_metric_kernel_properties_full_size():
-    # size-independent properties at BASELINE's 4096 x 4096: a constant stays constant (sum w = 1),
-    # and the operator is linear: R(a + b) ~= R(a) + R(b)
-    side = 4096
+@pytest.mark.parametrize("side", [4096, 8192])
+def test_metric_kernel_properties_full_size(side):
+    # size-independent properties at BASELINE's 4096 x 4096 and at the 8192 x 8192 bench.py also times: a constant stays
+    # constant (sum w = 1), and the operator is linear: R(a + b) ~= R(a) + R(b)
     p = _proc(64, 4)
     const = np.full((1, side, side), 0.75, dtype=np.float32)
     out = p.k_reduce_host(const)
-    assert out.shape == (1, 2048, 2048)
+    assert out.shape == (1, side // 2, side // 2)
     assert np.abs(out - 0.75).max() <= 2e-7
-    rng = np.random.default_rng(4096)
+    rng = np.random.default_rng(side)
     a = rng.random((1, side, side), dtype=np.float32)
     b = rng.random((1, side, side), dtype=np.float32)
     ra, rb, rab = p.k_reduce_host(a), p.k_reduce_host(b), p.k_reduce_host(a + b)
@@ -779,3 +779,24 @@ def test_native_pipeline_of_the_c_abi(ob):
     one.sync()
     _same(one.last().image(mp.IMG_GRADED), want[0].image(ob.IMG_GRADED), "graded (depth 1)")
     one.cleanup()
+
+
+@pytest.mark.parametrize("n,batch", [(16, 1), (333, 3), (1000, 2), (2048, 2)])
+def test_minmax_two_stage_edge_cases(ob, n, batch):
+    """k_minmax_u16 (two stages: per-block slots + the last ticket holder folds them; the step's clears in the same launch) on
+    sizes with one block, with images that start at odd byte offsets inside the batch (odd N: the scalar path), with several
+    trips per block, on extreme pixel values, and twice in a row (the ticket must be back at 0, the histograms cleared again)."""
+    rng = np.random.default_rng(n)
+    px = rng.integers(1000, 60000, size=(batch, n, n), dtype=np.uint16)
+    px[0, n // 2, n // 3] = 65535
+    px[batch - 1, n - 1, n - 1] = 7
+    if batch > 1:
+        px[1, 0, 0] = 0
+    p = _proc(n, 4 if n < 64 else 5, batch=batch)
+    for rep in range(2):
+        assert p.execute(px if batch > 1 else px[0]), mp.last_error()
+        for k in range(batch):
+            o = ob.Oracle(n, p.pyramidLevels, ob.ORDER_FAST).execute(px[k])
+            assert p.minmax(k) == o.minmax(), "image %d rep %d" % (k, rep)
+            assert np.array_equal(p.noise_hist(0, k), o.noise_hist(0)) and np.array_equal(p.grad_hist(k), o.grad_hist())
+    p.cleanup()
