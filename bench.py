@@ -147,7 +147,7 @@ def self_launch(args):
     print(line)
 
 
-def measure_metric_traffic(timeout=150):
+def measure_metric_traffic(timeout=90):
     """HBM-side bytes per launch of the stand-alone metric kernel at 4096^2 from HBM, collected NOW: two rocprofv3 passes
     (FETCH_SIZE and WRITE_SIZE cannot share a pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots') of devtools/pmc_metric_target.py as child
     processes, --pmc with no trace option. Units and corrections as that guide prescribes for gfx950: both counters are KiB; FETCH_SIZE
