@@ -14,8 +14,11 @@ constexpr int kT = MUSICA_CLAHE_TILES;
 constexpr int kB = MUSICA_CLAHE_BINS;
 
 // K22 clahe_histogram.comp:13-45 — hist[tx][ty][bin] += 1 where relevant == 1.0.
-// One workgroup per band of 8 consecutive rows (a band touches one or two tile rows, so its flush is short; the
-// LDS copy still holds all 16 tiles), 4 columns per thread with 16-byte loads.
+// One workgroup per band of `band` consecutive rows (8 at most: a band touches one or two tile rows, so its flush is short; the
+// LDS copy still holds all 16 tiles; fewer rows where 8 would leave the launch under ~2048 workgroups — one 4096^2 image:
+// 512 workgroups of 8 rows walked their 32 dependent load trips at 2 TB/s, 51 -> 36 us), 4 columns per thread with 16-byte loads.
+// (Measured and not kept: an LDS copy of only the two tile rows a band can touch — 41 us; the two serial float chains of
+// k_clahe_curve on v_readlane instead of thread 0 walking LDS — 22 against 13 us; 16 instead of 8 rows per k_clahe_apply4 band.)
 // RAWREL: the relevant value is computed here (relevant_of() on the cnr texel and `raw <= thr090` standing for
 // `normalized <= 0.9`, as in k_relevant4<true>) instead of read from a stored relevant image: 6 B/px instead of 8, and the
 // context's hot path writes no relevant image at all (musica_get_image computes it on demand). N % 4 == 0.
@@ -23,7 +26,7 @@ template <bool RAWREL>
 __global__ __launch_bounds__(256) void k_clahe_hist(const float* __restrict__ img, const float* __restrict__ relevant, int N, int pitch,
                                                     size_t plane, uint32_t* __restrict__ hist, const uint16_t* __restrict__ raw,
                                                     const int* __restrict__ thr090, const float* __restrict__ cnr, int cnrS, int cnrPitch,
-                                                    size_t cnrPlane, int cnrScale) {
+                                                    size_t cnrPlane, int cnrScale, int band) {
     __shared__ uint32_t lh[kT * kT * kB];
     for (int i = threadIdx.x; i < kT * kT * kB; i += blockDim.x) lh[i] = 0u;
     __syncthreads();
@@ -31,7 +34,7 @@ __global__ __launch_bounds__(256) void k_clahe_hist(const float* __restrict__ im
     if (!RAWREL) relevant += (size_t)blockIdx.z * plane;
     const int thr = RAWREL ? thr090[blockIdx.z] : 0;
     const float fN = (float)N;
-    for (int y = blockIdx.x * 8; y < min(blockIdx.x * 8 + 8, N); y++) {
+    for (int y = blockIdx.x * band; y < min(blockIdx.x * band + band, N); y++) {
         const uint32_t ty = f2u((float)y / fN * (float)kT);                      // :35
         const float* irow = img + (size_t)y * pitch;
         for (int x0 = threadIdx.x * 4; x0 < N; x0 += blockDim.x * 4) {
@@ -276,12 +279,14 @@ __global__ __launch_bounds__(256) void k_clahe_apply4(const float* __restrict__ 
 
 void launch_clahe(hipStream_t st, const float* img, const float* relevant, float* out, const LevelDesc& l0, uint32_t* hist, musica_point* pts,
                   int batch, const uint16_t* raw, const int* thr090, const float* cnr, const LevelDesc* l3, int cnrScale) {
-    const dim3 hgrid((l0.S + 7) / 8, 1, batch);
+    int band = 8;
+    while (band > 1 && (long)((l0.S + band - 1) / band) * batch < 2048) band >>= 1;
+    const dim3 hgrid((l0.S + band - 1) / band, 1, batch);
     if (raw && thr090 && cnr && l3 && (l0.S & 3) == 0 && cnrScale > 0 && (cnrScale & 3) == 0)   // relevant image computed on the fly
         hipLaunchKernelGGL(k_clahe_hist<true>, hgrid, dim3(256), 0, st, img, relevant, l0.S, l0.pitch, l0.plane, hist, raw, thr090, cnr, l3->S, l3->pitch,
-                           l3->plane, cnrScale);
+                           l3->plane, cnrScale, band);
     else
-        hipLaunchKernelGGL(k_clahe_hist<false>, hgrid, dim3(256), 0, st, img, relevant, l0.S, l0.pitch, l0.plane, hist, raw, thr090, cnr, 0, 0, (size_t)0, 0);
+        hipLaunchKernelGGL(k_clahe_hist<false>, hgrid, dim3(256), 0, st, img, relevant, l0.S, l0.pitch, l0.plane, hist, raw, thr090, cnr, 0, 0, (size_t)0, 0, band);
     hipLaunchKernelGGL(k_clahe_curve, dim3(kT * kT, batch), dim3(kB), 0, st, hist, pts);
     if ((l0.S & 3) == 0)
         hipLaunchKernelGGL(k_clahe_apply4, dim3((l0.S / 4 + 255) / 256, (l0.S + kApplyRows - 1) / kApplyRows, batch), dim3(256), 0, st, img, out, l0.S, l0.pitch, l0.plane, pts);

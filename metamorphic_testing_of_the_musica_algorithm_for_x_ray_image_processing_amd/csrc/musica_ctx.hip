@@ -728,18 +728,28 @@ static void enqueue_expand(musica_ctx* c, bool with_hist) {
 // stage "grad" (src/vk_processing.cpp:2456-2518)
 // fused: the level-0 expand launch has already accumulated the histogram (run_expand_level_h with_hist); what is left of K18 + K19 is
 // the literal recount of images that hold an exact zero (a launch that returns at once for every other image).
-static void enqueue_gradation(musica_ctx* c, bool fused) {
+// beside: the three-stream form runs the CLAHE block (it reads the reconstruction and feeds nothing of this step) on the side stream,
+// next to the gradation chain (histogram recount, curve, apply), instead of in front of it
+static void enqueue_gradation(musica_ctx* c, bool fused, bool beside = false) {
     fused = fused && c->fuse_gh && !c->generic;
     const LevelDesc& l0 = c->lv[0];
     const LevelDesc& l3 = c->lv[MUSICA_CNR_LEVEL];
     const int scale = (int)cnr_scale(l0.S, l3.S);
+    beside = beside && c->d_clahe_hist && c->side && c->clahe_raw;
     if (c->d_clahe_hist) {  // #ifdef ENABLE_CLAHE block, src/vk_processing.cpp:2471-2489
-        if (c->clahe_raw) {   // relevance computed inside the histogram launch from the raw pixels: no relevant image on the hot path
-            launch_clahe(c->stream, c->d_recon[0], nullptr, c->d_clahe_graded, l0, c->d_clahe_hist, c->d_clahe_pts, c->B, c->cur_input, c->d_thr090, c->d_cnr, &l3, scale);
-        } else {
-            launch_relevant(c->stream, c->d_norm, c->d_cnr, c->d_scratch, l0, l3, scale, c->B);
-            launch_clahe(c->stream, c->d_recon[0], c->d_scratch, c->d_clahe_graded, l0, c->d_clahe_hist, c->d_clahe_pts, c->B);
+        hipStream_t cs = c->stream;
+        if (beside) {
+            hipEventRecord(c->ev_fork, c->stream);       // both events have done their duty earlier in the step
+            hipStreamWaitEvent(c->side, c->ev_fork, 0);
+            cs = c->side;
         }
+        if (c->clahe_raw) {   // relevance computed inside the histogram launch from the raw pixels: no relevant image on the hot path
+            launch_clahe(cs, c->d_recon[0], nullptr, c->d_clahe_graded, l0, c->d_clahe_hist, c->d_clahe_pts, c->B, c->cur_input, c->d_thr090, c->d_cnr, &l3, scale);
+        } else {
+            launch_relevant(cs, c->d_norm, c->d_cnr, c->d_scratch, l0, l3, scale, c->B);
+            launch_clahe(cs, c->d_recon[0], c->d_scratch, c->d_clahe_graded, l0, c->d_clahe_hist, c->d_clahe_pts, c->B);
+        }
+        if (beside) hipEventRecord(c->ev_join, c->side);
     }
     {
         Span sp(c, MUSICA_KERNEL_GRAD_HIST);
@@ -759,6 +769,7 @@ static void enqueue_gradation(musica_ctx* c, bool fused) {
         launch_grad_curve(c->stream, c->d_grad_hist, c->d_grad_max, c->d_gcurve, c->B, fused ? c->d_grad_hist_b : nullptr, fused ? c->d_gzero : nullptr);
     }
     { Span sp(c, MUSICA_KERNEL_GRAD_APPLY); launch_grad_apply(c->stream, c->d_recon[0], c->d_graded, l0, c->d_gcurve, c->B); }
+    if (beside) hipStreamWaitEvent(c->stream, c->ev_join, 0);
 }
 
 // Three-stream form of the dispatch script (dag == 1, the default for batches and large images). The reference submits
@@ -830,7 +841,7 @@ static void enqueue_dag(musica_ctx* c) {
         Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
         run_expand_level(c, lvl, c->rows_expand[lvl]);
     }
-    enqueue_gradation(c, true);
+    enqueue_gradation(c, true, true);
 }
 
 // One in-order stream, the order of the reference's command buffer (dag == 0).
