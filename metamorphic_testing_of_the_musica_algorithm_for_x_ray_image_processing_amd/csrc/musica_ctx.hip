@@ -157,7 +157,10 @@ static bool dalloc(musica_ctx* c, T** out, size_t count) {
     void* p = nullptr;
     if (count == 0) count = 1;
     if (hipMalloc(&p, count * sizeof(T)) != hipSuccess) return false;
-    if (hipMemset(p, 0, count * sizeof(T)) != hipSuccess) { hipFree(p); return false; }  // "never-written texels read as 0" (Q2)
+    // "never-written texels read as 0" (Q2). hipMemset runs on the null stream, which the context's non-blocking streams do not wait for:
+    // drain it here, or a buffer allocated on first use (the 8-bit output, the second input buffer) could be zeroed AFTER the first
+    // kernel or copy has written it (seen once as zero rows at the top of saveOutImage's pixels)
+    if (hipMemset(p, 0, count * sizeof(T)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { hipFree(p); return false; }
     c->allocations.push_back(p);
     *out = (T*)p;
     return true;
@@ -439,10 +442,17 @@ static musica_ctx* create_impl(const musica_params* params) {
     // order — the form for contexts whose steps run beside other contexts' steps (musica_pipeline_*): such a context
     // creates ONE stream, so that the runtime's round-robin puts consecutive contexts on different hardware queues
     // (4 by default), and nothing of a step ever waits for an event of another queue. Both forms replay a captured hipGraph.
-    // (a pyramid with a long tail of tiny levels — the reference's own 3072^2 / L = 12 — is faster on one stream: 0.297 against 0.318 ms)
-    c->dag = (params->flags & MUSICA_FLAG_LINEAR) ? 0 : env_int("MUSICA_DAG", L >= 11 ? 0 : 1);
+    // Defaults for a context that runs alone (no MUSICA_FLAG_LINEAR, i.e. not one of a pipeline's): a step whose launches are mostly
+    // smaller than their fixed cost — up to one 3072^2 image — runs fastest as eager launches on ONE stream (one 2048^2 image / L6:
+    // 0.164 ms against 0.173 for the graph replay of either form and 0.181 for eager three-stream; 1024^2: 0.121 / 0.124 - 0.131;
+    // 3072^2 / L12: 0.290 / 0.298 - 0.318): a graph node costs more than a kernel launched behind its predecessor, and the side
+    // streams' joins more than they hide. A CLAHE context keeps the three-stream form (its CLAHE block runs beside the gradation
+    // chain); larger steps keep the graph (8 x 2048^2: 4 % faster than eager) and three streams, except pyramids of 11 or more levels.
+    const bool small_step = (size_t)c->B * N * N <= (size_t)3072 * 3072 && !(params->flags & MUSICA_FLAG_CLAHE);
+    const bool lone = !(params->flags & MUSICA_FLAG_LINEAR);
+    c->dag = (params->flags & MUSICA_FLAG_LINEAR) ? 0 : env_int("MUSICA_DAG", (L >= 11 || small_step) ? 0 : 1);
     if (c->dag < 0 || c->dag > 1) c->dag = 1;
-    c->use_graph = !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", 1) != 0;
+    c->use_graph = !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", (lone && small_step) ? 0 : 1) != 0;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     if (c->dag) {
         ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;

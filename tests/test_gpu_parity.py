@@ -83,8 +83,14 @@ def _compare_all(p, o, ob, idx=0, tag=""):
 CASES = [(512, 4, 1), (512, 0, 2), (256, 0, 3), (200, 5, 4), (1000, 6, 5), (333, 0, 6), (1024, 6, 7), (2048, 6, 8), (1792, 0, 9)]
 
 
+@pytest.mark.parametrize("dispatch", ["default", "graph3"])
 @pytest.mark.parametrize("n,levels,seed", CASES)
-def test_pipeline_bit_exact_vs_fast_oracle(ob, n, levels, seed):
+def test_pipeline_bit_exact_vs_fast_oracle(ob, n, levels, seed, dispatch, monkeypatch):
+    # "default": what musica_create picks for a lone context of this size (one image up to 3072^2: eager launches on one
+    # stream); "graph3": the captured three-stream graph that larger steps replay
+    if dispatch == "graph3":
+        monkeypatch.setenv("MUSICA_GRAPH", "1")
+        monkeypatch.setenv("MUSICA_DAG", "1")
     px = phantom(n, seed)
     o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px)
     p = _proc(n, levels)
@@ -138,6 +144,8 @@ def test_image_groups_give_the_same_bits(ob, flags, monkeypatch):
     run bit for bit, every getter addresses the right image, and per-kernel profiling still counts every launch."""
     n, levels, b = 520, 5, 5
     px = np.stack([phantom(n, 500 + k) for k in range(b)])
+    monkeypatch.setenv("MUSICA_DAG", "1")      # image groups are a feature of the three-stream form (a batch this small defaults to one stream)
+    monkeypatch.setenv("MUSICA_GRAPH", "1")
     monkeypatch.setenv("MUSICA_GROUPS", "1")
     one = _proc(n, levels, batch=b, flags=flags)
     monkeypatch.setenv("MUSICA_GROUPS", "3")
@@ -665,11 +673,12 @@ def test_steps_in_flight_on_three_contexts_are_the_lone_contexts_steps(ob):
 
 
 @pytest.mark.parametrize("nbuf", [3, 6])
-def test_rotating_caller_owned_device_buffers_without_syncing(ob, nbuf):
+def test_rotating_caller_owned_device_buffers_without_syncing(ob, nbuf, monkeypatch):
     """A caller that rotates its own device buffers through ONE context (musica_execute_device never waits): every distinct
     input pointer gets a captured graph, a context keeps four of them, and with more the least recently used executable graph
     is only destroyed after the stream has drained — 3 buffers replay, 6 recapture on every step; either way every step's
     result is the oracle's."""
+    monkeypatch.setenv("MUSICA_GRAPH", "1")    # a context this small would launch eagerly by default: the graph slots are what is tested
     n, levels = 520, 5
     imgs = [phantom(n, 4000 + k) for k in range(nbuf)]
     want = [ob.Oracle(n, levels, ob.ORDER_FAST).execute(im).image(ob.IMG_GRADED) for im in imgs]
