@@ -280,7 +280,7 @@ int main(int argc, char** argv) {
         {"prod", l_prod<4>},
         {"up_r4", l_up<4, 4, 0>}, {"up_r4_nts", l_up<4, 4, 1>}, {"up_r4_ntl", l_up<4, 4, 2>}, {"up_r6", l_up<6, 3, 0>}, {"up_r8", l_up<8, 2, 0>}, {"up_r2", l_up<2, 4, 0>}, {"up_r3", l_up<3, 4, 0>},
         {"lds_rt4_nts", l_lds<4, 4, 2, 0, 0, 0>}, {"lds_rt4_nts_ntli", l_lds<4, 4, 2, 2, 0, 0>}, {"lds_rt8_nts", l_lds<8, 4, 2, 0, 0, 0>}, {"lds_rt8_nts_ntli", l_lds<8, 4, 2, 2, 0, 0>},
-        {"lds_rt8_w8", l_lds<8, 8, 2, 0, 0, 0>}, {"lds_rt8_w8_ntli", l_lds<8, 8, 2, 2, 0, 0>}, {"lds_rt6_w3", l_lds<6, 3, 2, 0, 0, 0>}, {"lds_rt6_w3_ntli", l_lds<6, 3, 2, 2, 0, 0>},
+        {"lds_rt8_w8", l_lds<8, 8, 2, 0, 0, 0>}, {"lds_rt8_w8_ntli", l_lds<8, 8, 2, 2, 0, 0>}, {"lds_rt3_w3_ntli", l_lds<3, 3, 2, 2, 0, 0>}, {"lds_rt5_w5_ntli", l_lds<5, 5, 2, 2, 0, 0>}, {"lds_rt4_w2_ntli", l_lds<4, 2, 2, 2, 0, 0>}, {"lds_rt2_w2_ntli", l_lds<2, 2, 2, 2, 0, 0>}, {"lds_rt6_w3", l_lds<6, 3, 2, 0, 0, 0>}, {"lds_rt6_w3_ntli", l_lds<6, 3, 2, 2, 0, 0>},
         {"copy41", l_copy41}, {"copy41x2", l_copy41x2}, {"copy41_nts", l_copy41nt},
     };
     const size_t ip = (size_t)S * S, op = (size_t)So * So;
