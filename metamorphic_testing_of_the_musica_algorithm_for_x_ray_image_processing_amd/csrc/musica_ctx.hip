@@ -1683,7 +1683,11 @@ musica_pipeline* musica_pipeline_create(const musica_params* params, uint32_t de
         if (depth > 1) q.flags |= MUSICA_FLAG_LINEAR;
         const uint32_t n = (depth > 1 && depth < MUSICA_PIPELINE_QUEUES) ? MUSICA_PIPELINE_QUEUES : depth;
         for (uint32_t k = 0; k < n; k++) {
-            musica_ctx* c = musica_create(&q);
+            // the contexts are identical: the launch geometry the first one tuned is copied to the others instead of tuned again
+            musica_params qk = q;
+            if (k > 0) qk.flags |= MUSICA_FLAG_NO_AUTOTUNE;
+            musica_ctx* c = musica_create(&qk);
+            if (c && k > 0) { copy_rows(c, pl->ctx[0]); c->p.flags = q.flags; }
             if (!c) {
                 // the contexts beyond `depth` only exist for the queue calibration: without them (e.g. device memory is short at a
                 // large N) the first `depth` stay and prime() has nothing to choose from
