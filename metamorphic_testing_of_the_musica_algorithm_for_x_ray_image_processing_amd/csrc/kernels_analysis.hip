@@ -311,19 +311,16 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
+// one run: `band` / `sdev` / `hist` are the image's own plane and histogram, `tile` the run's 512-column strip and 16-row block
 template <bool A8>
-__global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_run(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
-                                                                 size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov, int swz) {
-    __shared__ uint32_t lh[kHistLdsWords];
-    __shared__ unsigned long long nzw[kWavesPerBlock][8];
+__device__ __forceinline__ void sdev_run_block(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch, size_t plane,
+                                               uint32_t* __restrict__ hist, int cov, const Tile tile, uint32_t* lh,
+                                               unsigned long long (*nzw)[8]) {
     hist_lds_clear(lh);
-    const int img = blockIdx.z;
-    const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
-    sdev += (size_t)img * plane;
+    const Buf bb = make_buf(band, plane * 4);
     const Buf db = make_buf(sdev, plane * 4);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const Tile tile = xcd_tile(swz);
     const int y0 = tile.segblock * kHistArea + wave * kRunRowsPerWave;   // wave-uniform
     const SCfg g = make_scfg(tile.strip, lane, S);
     const uint32_t rb = (uint32_t)pitch * 4u;
@@ -382,7 +379,34 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_run(const float* __
         }
     }
     __syncthreads();
-    hist_lds_flush(lh, hist + (size_t)img * hist_stride);
+    hist_lds_flush(lh, hist);
+}
+
+template <bool A8>
+__global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_run(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
+                                                                 size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov, int swz) {
+    __shared__ uint32_t lh[kHistLdsWords];
+    __shared__ unsigned long long nzw[kWavesPerBlock][8];
+    const size_t img = blockIdx.z;
+    sdev_run_block<A8>(band + img * plane, sdev + img * plane, S, pitch, plane, hist + img * hist_stride, cov, xcd_tile(swz), lh, nzw);
+}
+
+// The runs of SEVERAL levels in one launch (levels whose launch of their own would be a few dozen workgroups: a context
+// that runs alone pays ~5 us of fixed cost per launch and the four sdev launches of a step depend on nothing but their
+// own band image). Workgroups first .. first + strips * blocks - 1 of grid.x belong to level k; the finest level first.
+template <bool A8>
+__global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_runs(const SdevRunLevels a, size_t hist_stride, int cov) {
+    __shared__ uint32_t lh[kHistLdsWords];
+    __shared__ unsigned long long nzw[kWavesPerBlock][8];
+    int k = 0;
+    for (int j = 1; j < a.n; j++) k = (int)blockIdx.x >= a.l[j].first ? j : k;   // block-uniform
+    const SdevRunLevel& l = a.l[k];
+    const int local = (int)blockIdx.x - l.first;
+    Tile tile;
+    tile.strip = local % l.strips;
+    tile.segblock = local / l.strips;
+    const size_t img = blockIdx.z;
+    sdev_run_block<A8>(l.band + img * l.plane, l.sdev + img * l.plane, l.S, l.pitch, l.plane, l.hist + img * hist_stride, cov, tile, lh, nzw);
 }
 
 // histogram only (kernel-level parity tests feed a foreign sdev image): same scan, no stencil.
@@ -749,6 +773,25 @@ void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const Leve
     const dim3 grid(strips, (segs + kWavesPerBlock - 1) / kWavesPerBlock, batch);
     if ((l.S & 7) == 0) hipLaunchKernelGGL((k_sdev_hist_pf<true, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave, xcd_swizzle_on());
     else hipLaunchKernelGGL((k_sdev_hist_pf<true, false>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, hist, hist_stride, cov, rows_per_wave, xcd_swizzle_on());
+}
+
+void launch_sdev_hist_runs(hipStream_t st, int n, const float* const* band, float* const* sdev, const LevelDesc* lv, uint32_t* const* hist,
+                           size_t hist_stride, int cov, int batch) {
+    SdevRunLevels a;
+    a.n = n;
+    int first = 0;
+    bool a8 = true;
+    for (int k = 0; k < n; k++) {
+        const LevelDesc& l = lv[k];
+        const int strips = (l.S + kStripCols - 1) / kStripCols;
+        a.l[k] = SdevRunLevel{band[k], sdev[k], hist[k], l.plane, l.S, l.pitch, strips, first};
+        first += strips * ((l.S + kHistArea - 1) / kHistArea);
+        a8 = a8 && (l.S & 7) == 0;
+    }
+    for (int k = n; k < kSdevRunLevelsMax; k++) a.l[k] = a.l[0];
+    const dim3 grid(first, 1, batch);
+    if (a8) hipLaunchKernelGGL((k_sdev_hist_runs<true>), grid, dim3(kBlockThreads), 0, st, a, hist_stride, cov);
+    else hipLaunchKernelGGL((k_sdev_hist_runs<false>), grid, dim3(kBlockThreads), 0, st, a, hist_stride, cov);
 }
 
 void launch_sdev_literal(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, int batch) {

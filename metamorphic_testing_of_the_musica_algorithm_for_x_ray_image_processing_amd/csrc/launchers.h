@@ -84,6 +84,9 @@ void launch_minmax(hipStream_t st, const uint16_t* px, int N, uint32_t* minmax, 
 void launch_normalize(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, const uint32_t* minmax, int min_chain_exact, int batch);
 void launch_sqrt(hipStream_t st, const uint16_t* px, float* out, const LevelDesc& l0, int batch);
 void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch, int rows_per_wave);
+// the 16-row-run form of launch_sdev_hist for n <= kSdevRunLevelsMax levels in ONE launch (hist[k]: image 0's histogram of level k)
+void launch_sdev_hist_runs(hipStream_t st, int n, const float* const* band, float* const* sdev, const LevelDesc* lv, uint32_t* const* hist,
+                           size_t hist_stride, int cov, int batch);
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch);
 // img_sdev.comp:10-35 with the 25 squares accumulated in the shader's order (one thread per texel; MUSICA_FLAG_REFERENCE_ORDER)
 void launch_sdev_literal(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, int batch);

@@ -670,19 +670,42 @@ static void enqueue_reduce(musica_ctx* c) {
 }
 
 // stage "anly" (src/vk_processing.cpp:2284-2357)
+// levels first .. MUSICA_CNR_LEVEL of sdev + noise histogram in one launch (their launches depend on nothing but their own
+// band image, and the 16-row-run form of a small level is a few dozen workgroups)
+static void run_sdev_levels(musica_ctx* c, int first) {
+    const float* band[kSdevRunLevelsMax];
+    float* sdev[kSdevRunLevelsMax];
+    uint32_t* hist[kSdevRunLevelsMax];
+    LevelDesc lv[kSdevRunLevelsMax];
+    int n = 0;
+    for (int i = first; i <= MUSICA_CNR_LEVEL; i++, n++) {
+        band[n] = c->d_band[i]; sdev[n] = c->d_sdev[i]; lv[n] = c->lv[i];
+        hist[n] = c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS;
+    }
+    launch_sdev_hist_runs(c->cur, n, band, sdev, lv, hist, (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov, c->B);
+}
+// the first level from which every sdev launch is the 16-row-run form (MUSICA_CNR_LEVEL + 1: none)
+static int sdev_runs_from(const musica_ctx* c) {
+    if (c->ref_order) return MUSICA_CNR_LEVEL + 1;
+    int first = MUSICA_CNR_LEVEL + 1;
+    while (first > 0 && c->rows_sdev[first - 1] <= 0) first--;
+    return first;
+}
 static void enqueue_analysis(musica_ctx* c) {
-    for (int i = 0; i <= MUSICA_CNR_LEVEL; i++) {  // i < coarserLevelsStart || i <= cnrLevel, :2285
+    int merged = sdev_runs_from(c);
+    if (merged >= MUSICA_CNR_LEVEL) merged = MUSICA_CNR_LEVEL + 1;   // one level is its own launch
+    for (int i = 0; i < merged; i++) {  // i < coarserLevelsStart || i <= cnrLevel, :2285
         Span sp(c, MUSICA_KERNEL_SDEV_HIST);
         run_sdev_level(c, i, c->rows_sdev[i]);
     }
-    {
-        Span sp(c, MUSICA_KERNEL_CURVES);
-        launch_noise_curves(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts, c->d_minmax,
-                            c->min_chain_exact, c->d_thr090);
+    if (merged <= MUSICA_CNR_LEVEL) {
+        Span sp(c, MUSICA_KERNEL_SDEV_HIST);
+        run_sdev_levels(c, merged);
     }
-    {
-        Span sp(c, MUSICA_KERNEL_CNR);
-        launch_cnr(c->stream, c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_noise_max, c->L, c->B);
+    {   // curves of every level + cnr of level 3 in one launch (kernels_analysis.hip k_curves_cnr)
+        Span sp(c, MUSICA_KERNEL_CURVES);
+        launch_curves_cnr(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
+                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_thr090);
     }
 }
 

@@ -79,6 +79,20 @@ struct LevelDesc {
     size_t plane;   // floats per image plane = pitch * S
 };
 
+// the levels of one k_sdev_hist_runs launch (kernels_analysis.hip): workgroups first .. of grid.x take level k's runs
+constexpr int kSdevRunLevelsMax = 4;
+struct SdevRunLevel {
+    const float* band;
+    float* sdev;
+    uint32_t* hist;   // image 0's histogram of this level
+    size_t plane;
+    int S, pitch, strips, first;
+};
+struct SdevRunLevels {
+    SdevRunLevel l[kSdevRunLevelsMax];
+    int n;
+};
+
 static inline int round_up4(int v) { return (v + 3) & ~3; }
 
 }  // namespace musica
