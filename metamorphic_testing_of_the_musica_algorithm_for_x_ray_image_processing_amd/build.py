@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libmusica_hip.so")
 CLI = os.path.join(HERE, "musica-standalone")
 HIP_SOURCES = ["kernels_pyramid.hip", "kernels_analysis.hip", "kernels_gradation.hip", "kernels_clahe.hip", "kernels_bench.hip", "musica_ctx.hip"]
 CPP_SOURCES = ["musica_io.cpp"]
-HEADERS = ["musica_device.h", "kernels_common.h", "exact_math.h", "sdev_parts.h", "launchers.h", os.path.join("..", "..", "include", "musica.h")]
+HEADERS = ["musica_device.h", "kernels_common.h", "exact_math.h", "sdev_parts.h", "grad_parts.h", "launchers.h", os.path.join("..", "..", "include", "musica.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 

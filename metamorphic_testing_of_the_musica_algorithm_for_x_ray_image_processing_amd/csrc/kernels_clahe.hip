@@ -7,6 +7,7 @@
 // histogram image is cleared at the start of every execute.
 #include "kernels_common.h"
 #include "launchers.h"
+#include "grad_parts.h"
 
 namespace musica {
 
@@ -188,16 +189,6 @@ __global__ void k_clahe_apply(const float* __restrict__ in, float* __restrict__ 
 //    everything that depends on the row only (py, by, the vertical neighbour and weights) once per row, where it is wave-uniform;
 //  * per texel remain the four getY() lookups and the blend, in the shader's order: (bx,by), (bx+sx,by), (bx,by+sy), (bx+sx,by+sy).
 constexpr int kApplyRows = 8;
-__device__ __forceinline__ float clahe_get_y_lds(const float* __restrict__ ys /* [kB] ordinates of one tile */, float s) {
-    int j = 0;
-    if (s > 0.0f) j = (int)fminf(ceilf(s * (float)kB), (float)(kB - 1));
-    if (s > 1.0f) j += 1;
-    if (j == 0) return (s == 0.0f) ? ys[0] : 0.0f;
-    if (j >= kB) return 0.0f;
-    const float y0 = ys[j - 1], y1 = ys[j], x0 = clahe_x(j - 1);
-    const float m = (y1 - y0) * (j == kB - 1 ? (float)(kB / 2) : (float)kB);
-    return m * (s - x0) + y0;
-}
 // one axis of clahe_grad_curve_apply.comp:45-79 for texel coordinate v: p = v / G, base b = uint(p) + 0.5, d = p - b, the
 // neighbour b + sign(d); tile indices (the base one unclamped for the d == 0 case, both clamped for the blend) and the
 // weights 1 - |c - p| of the two candidates.
@@ -221,75 +212,153 @@ __device__ __forceinline__ ClaheAxis clahe_axis(int v, uint32_t G) {
     a.t1 = min(f2u(floorf(n)), (uint32_t)kT - 1u);
     return a;
 }
-__device__ __forceinline__ float clahe_blend(const float* __restrict__ ys, float pixel, const ClaheAxis& ax, const ClaheAxis& ay) {
-    if (!ax.use && !ay.use) {                                                    // :61-66
-        if (ax.t0_raw < (uint32_t)kT && ay.t0_raw < (uint32_t)kT) return clahe_get_y_lds(ys + ((size_t)ax.t0_raw * kT + ay.t0_raw) * kB, pixel);
-        return 0.0f;
-    }
+// ---- the apply kernels' hot path --------------------------------------------------------------------------------
+// The literal form (k_clahe_apply) costs ~100 vector instructions and a dozen branches per texel: at 4 columns per thread the
+// apply ran instruction-bound at 2.6 TB/s. Here:
+//  * the four getY() calls of a texel look the SAME s up in four tiles, so the segment index, s - x[j-1] and the slope factor are
+//    computed once per texel, and getY()'s three outcomes become one expression on a padded table — a tile's 256 ordinates are
+//    followed by two zeros:
+//      1 <= j < 256 : idx = j - 1,  t = s - idx / 256   ->  ((y[idx+1] - y[idx]) * mult) * t + y[idx]        (getY proper)
+//      s == 0       : idx = 0,      t = 0               ->  (..) * 0 + y[0] = y[0]                            (:29-31, x[0] == s)
+//      otherwise    : idx = 256,    t = 0               ->  (0 * mult) * 0 + 0 = 0                            (no segment: 0; NaN too)
+//    the same operations on the same values as clahe_get_y for the first case, the same results for the others (ordinates are >= 0
+//    or, for a tile without a relevant texel, NaN);
+//  * the shader's four cases (dx, dy zero or not: texels of the 4 columns / 4 rows through tile centres blend two tiles or take
+//    one) are the four-term sum with weights (1, 0) on an axis without a neighbour and the neighbour's tile index replaced by the
+//    base one: 1 * w = w and 0 + a = a are exact, a term 0 * w * g is +0 (g >= 0) or, for a NaN tile, the NaN the kept term of the
+//    same tile already put into the sum. So every texel runs the same straight-line code.
+constexpr int kYs = kB + 2;   // ordinates of one tile in LDS + two zeros
+struct ClaheRowLds { float w0, w1; int b0, b1; };   // one row: the two weights and kYs * tile row of the two candidates
+__device__ __forceinline__ void clahe_tables_to_lds(float* __restrict__ ys, const musica_point* __restrict__ P) {
+    for (int i = threadIdx.x; i < kT * kT * kB; i += blockDim.x) ys[(i / kB) * kYs + (i % kB)] = P[i].y;
+    if (threadIdx.x < kT * kT * 2) ys[(threadIdx.x >> 1) * kYs + kB + (threadIdx.x & 1)] = 0.0f;
+}
+struct ClaheLookup {
+    int idx;         // see above
+    float t, mult;   // s - x[idx] (0 where no segment); kB (kB / 2 for the last segment)
+};
+__device__ __forceinline__ ClaheLookup clahe_lookup(float s) {
+    const float cj = fminf(ceilf(s * (float)kB), (float)(kB - 1));
+    int j = s > 0.0f ? (int)cj : 0;
+    j += s > 1.0f ? 1 : 0;
+    const bool valid = (uint32_t)(j - 1) < (uint32_t)(kB - 1);   // 1 <= j < kB
+    ClaheLookup q;
+    q.idx = valid ? j - 1 : (s == 0.0f ? 0 : kB);
+    q.t = q.idx == kB ? 0.0f : s - (float)q.idx * (1.0f / (float)kB);   // clahe_x(j - 1), j - 1 <= 254
+    q.mult = j == kB - 1 ? (float)(kB / 2) : (float)kB;
+    return q;
+}
+__device__ __forceinline__ float clahe_y_at(const float* __restrict__ ys, int base, const ClaheLookup& q) {
+    const float y0 = ys[base + q.idx], y1 = ys[base + q.idx + 1];
+    return ((y1 - y0) * q.mult) * q.t + y0;
+}
+// one texel (:61-146): wx0 / wx1, bx0 / bx1 = the column's weights and kT * kYs * tile column of its two candidates, r = the row's
+__device__ __forceinline__ float clahe_blend_xy(const float* __restrict__ ys, float pixel, float wx0, float wx1, int bx0, int bx1, const ClaheRowLds& r) {
+    const ClaheLookup q = clahe_lookup(pixel);
     float combined = 0.0f;
-    if (ax.use && ay.use) {                                                      // :116-146: (bx,by) (bx+sx,by) (bx,by+sy) (bx+sx,by+sy)
-        combined += ax.w0 * ay.w0 * clahe_get_y_lds(ys + ((size_t)ax.t0 * kT + ay.t0) * kB, pixel);
-        combined += ax.w1 * ay.w0 * clahe_get_y_lds(ys + ((size_t)ax.t1 * kT + ay.t0) * kB, pixel);
-        combined += ax.w0 * ay.w1 * clahe_get_y_lds(ys + ((size_t)ax.t0 * kT + ay.t1) * kB, pixel);
-        combined += ax.w1 * ay.w1 * clahe_get_y_lds(ys + ((size_t)ax.t1 * kT + ay.t1) * kB, pixel);
-    } else if (ay.use) {                                                         // :68-88
-        combined += ay.w0 * clahe_get_y_lds(ys + ((size_t)ax.t0 * kT + ay.t0) * kB, pixel);
-        combined += ay.w1 * clahe_get_y_lds(ys + ((size_t)ax.t0 * kT + ay.t1) * kB, pixel);
-    } else {                                                                     // :94-114
-        combined += ax.w0 * clahe_get_y_lds(ys + ((size_t)ax.t0 * kT + ay.t0) * kB, pixel);
-        combined += ax.w1 * clahe_get_y_lds(ys + ((size_t)ax.t1 * kT + ay.t0) * kB, pixel);
-    }
+    combined += wx0 * r.w0 * clahe_y_at(ys, bx0 + r.b0, q);
+    combined += wx1 * r.w0 * clahe_y_at(ys, bx1 + r.b0, q);
+    combined += wx0 * r.w1 * clahe_y_at(ys, bx0 + r.b1, q);
+    combined += wx1 * r.w1 * clahe_y_at(ys, bx1 + r.b1, q);
     return combined;
 }
-// grid: x = 1024-column chunks, y = bands of kApplyRows rows, z = batch
-__global__ __launch_bounds__(256) void k_clahe_apply4(const float* __restrict__ in, float* __restrict__ out, int N, int pitch, size_t plane,
-                                                      const musica_point* __restrict__ points) {
-    __shared__ float ys[kT * kT * kB];
-    const musica_point* P = points + (size_t)blockIdx.z * kT * kT * kB;
-    const int y0 = blockIdx.y * kApplyRows;
-    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const uint32_t G = (uint32_t)N / (uint32_t)kT;                               // :43
-    in += (size_t)blockIdx.z * plane;
-    out += (size_t)blockIdx.z * plane;
-    const bool active = x < N;
-    // the first row's group is requested before the ordinates are staged
-    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (active) v = *reinterpret_cast<const float4*>(in + (size_t)y0 * pitch + x);
-    for (int i = threadIdx.x; i < kT * kT * kB; i += blockDim.x) ys[i] = P[i].y;
-    ClaheAxis ax[4];
+
+// K24 (GRAD = 0) or K21 + K24 in one pass over the reconstruction (GRAD = 16 / 32 / 1: the tone curve by grad_eval4<16 / 32 / 0>).
+// The reference applies the tone curve (img_apply_gradation_curve.comp) and the CLAHE curves (clahe_grad_curve_apply.comp) in two
+// dispatches that each read the whole image; with GRAD a texel is read once and both results are stored (12 instead of 16 bytes
+// per texel, one launch).
+template <int GRAD>
+__device__ __forceinline__ void apply_rows(const float* __restrict__ in, float* __restrict__ out_clahe, float* __restrict__ out_graded, int N, int pitch, int x,
+                                           int y0, const float* __restrict__ ys, const ClaheRowLds* __restrict__ rows, const ClaheAxis (&ax)[4],
+                                           const CurveLds& tab, const GradLds& gl, float4 v) {
+    const uint32_t last_b = tab.count ? (tab.count - 1u) * 4u : 0u;
+    const float gx0 = tab.x[0], gy0 = tab.y[0];
+    float wx0[4], wx1[4];
+    int bx0[4], bx1[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) ax[j] = clahe_axis(x + j, G);
-    __syncthreads();
-    if (!active) return;
+    for (int j = 0; j < 4; j++) {
+        wx0[j] = ax[j].use ? ax[j].w0 : 1.0f;
+        wx1[j] = ax[j].use ? ax[j].w1 : 0.0f;
+        bx0[j] = (int)ax[j].t0 * kT * kYs;
+        bx1[j] = (int)(ax[j].use ? ax[j].t1 : ax[j].t0) * kT * kYs;
+    }
     for (int r = 0; r < kApplyRows; r++) {
         const int y = y0 + r;
         if (y >= N) break;
         float4 nxt = v;
         if (r + 1 < kApplyRows && y + 1 < N) nxt = *reinterpret_cast<const float4*>(in + (size_t)(y + 1) * pitch + x);   // next row, in flight during the lookups
-        const ClaheAxis ay = clahe_axis(y, G);
+        if (GRAD) *reinterpret_cast<float4*>(out_graded + (size_t)y * pitch + x) = grad_eval4<(GRAD == 1 ? 0 : GRAD)>(tab, gl, last_b, gx0, gy0, v);
+        const ClaheRowLds rw = rows[r];
         float4 c;
-        c.x = clahe_blend(ys, v.x, ax[0], ay);
-        c.y = clahe_blend(ys, v.y, ax[1], ay);
-        c.z = clahe_blend(ys, v.z, ax[2], ay);
-        c.w = clahe_blend(ys, v.w, ax[3], ay);
-        *reinterpret_cast<float4*>(out + (size_t)y * pitch + x) = c;
+        c.x = clahe_blend_xy(ys, v.x, wx0[0], wx1[0], bx0[0], bx1[0], rw);
+        c.y = clahe_blend_xy(ys, v.y, wx0[1], wx1[1], bx0[1], bx1[1], rw);
+        c.z = clahe_blend_xy(ys, v.z, wx0[2], wx1[2], bx0[2], bx1[2], rw);
+        c.w = clahe_blend_xy(ys, v.w, wx0[3], wx1[3], bx0[3], bx1[3], rw);
+        *reinterpret_cast<float4*>(out_clahe + (size_t)y * pitch + x) = c;
         v = nxt;
     }
 }
+// grid: x = 1024-column chunks, y = bands of kApplyRows rows, z = batch. BOTH = false: K24 alone (curves / out_graded unused).
+template <bool BOTH, int W>
+__global__ __launch_bounds__(256, W) void k_clahe_apply4(const float* __restrict__ in, float* __restrict__ out_clahe, float* __restrict__ out_graded, int N, int pitch,
+                                                      size_t plane, const musica_point* __restrict__ points, const DevCurve* __restrict__ curves) {
+    __shared__ float ys[kT * kT * kYs];
+    __shared__ ClaheRowLds rows[kApplyRows];
+    __shared__ CurveLds tab;
+    __shared__ __attribute__((aligned(16))) GradLds gl;
+    const int y0 = blockIdx.y * kApplyRows;
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const uint32_t G = (uint32_t)N / (uint32_t)kT;                               // :43
+    in += (size_t)blockIdx.z * plane;
+    out_clahe += (size_t)blockIdx.z * plane;
+    if (BOTH) out_graded += (size_t)blockIdx.z * plane;
+    const bool active = x < N;
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (active) v = *reinterpret_cast<const float4*>(in + (size_t)y0 * pitch + x);   // the first row's group is requested before the tables are staged
+    clahe_tables_to_lds(ys, points + (size_t)blockIdx.z * kT * kT * kB);
+    if (BOTH) grad_tables_to_lds(tab, gl, curves + blockIdx.z);
+    if (threadIdx.x < kApplyRows) {   // the rows' axis values, once per workgroup
+        const ClaheAxis ay = clahe_axis(y0 + (int)threadIdx.x, G);
+        ClaheRowLds rw;
+        rw.w0 = ay.use ? ay.w0 : 1.0f; rw.w1 = ay.use ? ay.w1 : 0.0f;
+        rw.b0 = (int)ay.t0 * kYs; rw.b1 = (int)(ay.use ? ay.t1 : ay.t0) * kYs;
+        rows[threadIdx.x] = rw;
+    }
+    ClaheAxis ax[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) ax[j] = clahe_axis(x + j, G);
+    __syncthreads();
+    if (!active) return;
+    const int mono = BOTH ? __builtin_amdgcn_readfirstlane((int)tab.monotone) : 0, cnt = BOTH ? __builtin_amdgcn_readfirstlane((int)tab.count) : 0;
+    if (!BOTH) apply_rows<0>(in, out_clahe, out_graded, N, pitch, x, y0, ys, rows, ax, tab, gl, v);
+    else if (mono != 0 && cnt < 32) apply_rows<16>(in, out_clahe, out_graded, N, pitch, x, y0, ys, rows, ax, tab, gl, v);   // the 22-point tone curve, monotone unless t1 < ts
+    else if (mono != 0) apply_rows<32>(in, out_clahe, out_graded, N, pitch, x, y0, ys, rows, ax, tab, gl, v);
+    else apply_rows<1>(in, out_clahe, out_graded, N, pitch, x, y0, ys, rows, ax, tab, gl, v);
+}
+
+void launch_grad_clahe_apply(hipStream_t st, const float* img, float* out_clahe, float* out_graded, const LevelDesc& l0, const musica_point* pts,
+                             const DevCurve* curves, int batch) {
+    // W = 8: register allocation capped at 64 (8 wavefronts per SIMD, 52 bytes of scratch): 46 us for one 4096^2 image against 51 us at 88 registers
+    const dim3 grid((l0.S / 4 + 255) / 256, (l0.S + kApplyRows - 1) / kApplyRows, batch);
+    hipLaunchKernelGGL((k_clahe_apply4<true, 8>), grid, dim3(256), 0, st, img, out_clahe, out_graded, l0.S, l0.pitch, l0.plane, pts, curves);
+}
 
 void launch_clahe(hipStream_t st, const float* img, const float* relevant, float* out, const LevelDesc& l0, uint32_t* hist, musica_point* pts,
-                  int batch, const uint16_t* raw, const int* thr090, const float* cnr, const LevelDesc* l3, int cnrScale) {
+                  int batch, const uint16_t* raw, const int* thr090, const float* cnr, const LevelDesc* l3, int cnrScale, bool hist_done, bool with_apply) {
     int band = 8;
     while (band > 1 && (long)((l0.S + band - 1) / band) * batch < 2048) band >>= 1;
     const dim3 hgrid((l0.S + band - 1) / band, 1, batch);
-    if (raw && thr090 && cnr && l3 && (l0.S & 3) == 0 && cnrScale > 0 && (cnrScale & 3) == 0)   // relevant image computed on the fly
+    if (hist_done) {}   // the level-0 expand launch counted it (k_expand_fast<.., CH = true>)
+    else if (raw && thr090 && cnr && l3 && (l0.S & 3) == 0 && cnrScale > 0 && (cnrScale & 3) == 0)   // relevant image computed on the fly
         hipLaunchKernelGGL(k_clahe_hist<true>, hgrid, dim3(256), 0, st, img, relevant, l0.S, l0.pitch, l0.plane, hist, raw, thr090, cnr, l3->S, l3->pitch,
                            l3->plane, cnrScale, band);
     else
         hipLaunchKernelGGL(k_clahe_hist<false>, hgrid, dim3(256), 0, st, img, relevant, l0.S, l0.pitch, l0.plane, hist, raw, thr090, cnr, 0, 0, (size_t)0, 0, band);
     hipLaunchKernelGGL(k_clahe_curve, dim3(kT * kT, batch), dim3(kB), 0, st, hist, pts);
+    if (!with_apply) return;   // launch_grad_clahe_apply follows
     if ((l0.S & 3) == 0)
-        hipLaunchKernelGGL(k_clahe_apply4, dim3((l0.S / 4 + 255) / 256, (l0.S + kApplyRows - 1) / kApplyRows, batch), dim3(256), 0, st, img, out, l0.S, l0.pitch, l0.plane, pts);
+        hipLaunchKernelGGL((k_clahe_apply4<false, 5>), dim3((l0.S / 4 + 255) / 256, (l0.S + kApplyRows - 1) / kApplyRows, batch), dim3(256), 0, st, img, out, (float*)nullptr,
+                           l0.S, l0.pitch, l0.plane, pts, (const DevCurve*)nullptr);
     else
         hipLaunchKernelGGL(k_clahe_apply, dim3((l0.S + 31) / 32, (l0.S + 7) / 8, batch), dim3(32, 8), 0, st, img, out, l0.S, l0.pitch, l0.plane, pts);
 }

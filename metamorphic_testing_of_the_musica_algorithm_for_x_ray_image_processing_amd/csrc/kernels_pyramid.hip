@@ -815,8 +815,15 @@ __device__ __forceinline__ float curve_eval_lut(const CurveLds& t, const LutLds&
 // against thr090 (32 bytes).
 // CNR48: the cnr scale is 4 or 8 (levels 1 and 0 of every image side that is a multiple of 8): columns c..c+3 and c+4..c+7 of a
 // lane each sit under one cnr texel. Wave-uniform like LUTOK and chosen the same way (the other form divides per texel).
-template <int GAIN, bool NR, int T, bool GH, bool MASK, bool LUTOK, bool CNR48>
-__device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds& tab, const LutLds& lut, uint32_t* lh, int img) {
+// CH (with GH + MASK, CLAHE contexts): the launch also accumulates clahe_histogram.comp:13-45 — hist[tx][ty][bin] += 1 where
+// relevant == 1.0 — of the texels it reconstructs (k_clahe_hist<true> re-read the whole reconstruction and the raw pixels for it:
+// 36 us for one 4096^2 image). relevant == 1.0 is relevant_of()'s value spelled out: inside the border and either the ramp
+// value ((r*r)*(r*r))*r itself 1.0 or cnr in [6, 256] with `normalized <= 0.9`. A workgroup's 512 columns and its rows touch at
+// most 2 x 2 tiles (the launcher checks: tile side >= 512 and >= the workgroup's rows): lc = 2 copies x 4 tile slots x 256 bins.
+constexpr int kChSlots = 4, kChCopies = 2;
+template <int GAIN, bool NR, int T, bool GH, bool MASK, bool LUTOK, bool CNR48, bool CH = false>
+__device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds& tab, const LutLds& lut, uint32_t* lh, int img, uint32_t* lc = nullptr,
+                                             uint32_t tx0 = 0u, uint32_t ty0 = 0u) {
     constexpr int kGhCopies = 4, kGhStride = MUSICA_GRAD_BINS + 8;
     // slope of noise_reduction.comp:28, the same value for every texel
     const float nr_m = (a.highFactor - a.lowFactor) / (a.highCnr - a.lowCnr);
@@ -851,6 +858,14 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
     }
     const int thr = GH && !MASK ? a.thr090[img] : 0;
     uint32_t* lhc = lh + (GH ? (lane & (kGhCopies - 1)) * kGhStride : 0);
+    // CLAHE tile column of each of the lane's 8 columns, relative to the workgroup's first one (clahe_histogram.comp:34)
+    const float fS = (float)S;
+    uint32_t chx = 0u;
+    if (CH) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) chx |= (min(f2u((float)(g.c + j) / fS * (float)MUSICA_CLAHE_TILES) - tx0, 1u)) << j;
+    }
+    uint32_t* lcc = CH ? lc + (lane & (kChCopies - 1)) * (kChSlots * MUSICA_CLAHE_BINS) : nullptr;
 
     CRow cw[T + 2];
     load_crow(cw[0], pb, (uint32_t)coarse_of_fine(2 * k0 - 2, S) * crb, g);
@@ -905,6 +920,10 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
                 // img_relevant.comp:44-63 for the cnr texel above the row pair (rows 2kk, 2kk+1 and columns c..c+7 share it)
                 const CnrClass kc = classify_cnr(cnr_pair);
                 const uint32_t w_cnr = kc.ramp ? kc.w_ramp : 0u, w_dark_or_ramp = kc.ramp ? kc.w_ramp : (kc.high ? 100u : 0u);   // bright / dark pixel under this texel
+                // relevant == 1.0 (CH): the ramp value itself, else 1.0 for a dark pixel under a high-cnr texel (relevant_of)
+                const float r6 = cnr_pair / 6.0f;
+                const bool one_ramp = CH && kc.ramp && (((r6 * r6) * (r6 * r6)) * r6 == 1.0f);
+                const bool one_dark = CH && !kc.ramp && kc.high;
 #pragma unroll
                 for (int ph = 0; ph < 2; ph++) {   // even row, then odd row: each is stored (and binned) before the next is touched
                     float* b = ph ? bo[t] : be[t];
@@ -925,6 +944,7 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
                         const uint32_t dark = MASK ? le[t] >> (8 * ph) : 0u;
                         const uint32_t y = (uint32_t)(2 * kk + ph);
                         const uint32_t m = (y > border && y < lim) ? colin : 0u;   // inside-the-border bits of the lane's 8 columns in this row
+                        const uint32_t chy = CH ? min(f2u((float)y / fS * (float)MUSICA_CLAHE_TILES) - ty0, 1u) : 0u;   // clahe_histogram.comp:35 (wave-uniform)
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
                             const float cur = b[j];
@@ -938,6 +958,12 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
                             const bool le090 = MASK ? ((dark >> j) & 1u) != 0u : px <= thr;
                             const uint32_t w = ((m >> j) & 1u) * (le090 ? w_dark_or_ramp : w_cnr);
                             atomicAdd(&lhc[bin], w);
+                            if (CH) {
+                                const float scaled = cur * (float)(MUSICA_CLAHE_BINS - 1) + 0.5f;                 // clahe_histogram.comp:20
+                                const bool inrange = scaled > -1.0f && scaled < (float)MUSICA_CLAHE_BINS;       // NaN never indexes (Q6)
+                                if (((m >> j) & 1u) && inrange && (one_ramp || (one_dark && le090)))
+                                    atomicAdd(&lcc[((((chx >> j) & 1u) * 2u + chy) * MUSICA_CLAHE_BINS) + (uint32_t)(int)scaled], 1u);   // :39-44
+                            }
                         }
                     }
                 }
@@ -949,7 +975,7 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
     return saw_zero;
 }
 
-template <int GAIN, bool NR, int T, bool GH, int W = 1, bool MASK = false>
+template <int GAIN, bool NR, int T, bool GH, int W = 1, bool MASK = false, bool CH = false>
 __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) {
     __shared__ CurveLds tab;
     __shared__ __attribute__((aligned(16))) LutLds lut;
@@ -957,9 +983,17 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
     // and lanes of one ds_add that hit the same address are served one after the other); word 1024 of a copy takes what is out of range
     constexpr int kGhCopies = 4, kGhStride = MUSICA_GRAD_BINS + 8;
     __shared__ uint32_t lh[GH ? kGhCopies * kGhStride : 1];
+    __shared__ uint32_t lc[CH ? kChCopies * kChSlots * MUSICA_CLAHE_BINS : 1];
     const int img = blockIdx.z;
     if (GH)
         for (int i = threadIdx.x; i < kGhCopies * kGhStride; i += blockDim.x) lh[i] = 0u;
+    uint32_t tx0 = 0u, ty0 = 0u;   // CLAHE tile of the workgroup's first column / first row
+    if (CH) {
+        for (int i = threadIdx.x; i < kChCopies * kChSlots * MUSICA_CLAHE_BINS; i += blockDim.x) lc[i] = 0u;
+        const Tile t = xcd_tile(a.swz);
+        tx0 = f2u((float)(t.strip * kStripCols) / (float)a.S * (float)MUSICA_CLAHE_TILES);
+        ty0 = f2u((float)(t.segblock * kWavesPerBlock * a.rows_per_wave * 2) / (float)a.S * (float)MUSICA_CLAHE_TILES);
+    }
     if (GAIN == GAIN_CURVE) {
         const DevCurve* cv = a.curves + (size_t)img * a.curve_stride;
         const DevCurveLut* lv = a.luts + (size_t)img * MUSICA_COARSER_LEVELS_START;
@@ -973,10 +1007,10 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
     const bool lut_ok = GAIN != GAIN_CURVE || __builtin_amdgcn_readfirstlane((int)lut.ok) != 0;
     const bool cnr48 = !NR || GH || a.cnrScale == 4 || a.cnrScale == 8;   // kernel argument: uniform
     bool saw_zero;
-    if (lut_ok && cnr48) saw_zero = expand_march<GAIN, NR, T, GH, MASK, true, true>(a, tab, lut, lh, img);
-    else if (lut_ok) saw_zero = expand_march<GAIN, NR, T, GH, MASK, true, NR && !GH ? false : true>(a, tab, lut, lh, img);
-    else if (cnr48) saw_zero = expand_march<GAIN, NR, T, GH, MASK, GAIN != GAIN_CURVE, true>(a, tab, lut, lh, img);
-    else saw_zero = expand_march<GAIN, NR, T, GH, MASK, GAIN != GAIN_CURVE, NR && !GH ? false : true>(a, tab, lut, lh, img);
+    if (lut_ok && cnr48) saw_zero = expand_march<GAIN, NR, T, GH, MASK, true, true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
+    else if (lut_ok) saw_zero = expand_march<GAIN, NR, T, GH, MASK, true, NR && !GH ? false : true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
+    else if (cnr48) saw_zero = expand_march<GAIN, NR, T, GH, MASK, GAIN != GAIN_CURVE, true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
+    else saw_zero = expand_march<GAIN, NR, T, GH, MASK, GAIN != GAIN_CURVE, NR && !GH ? false : true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
     if (GH) {
         if (saw_zero) atomicOr(&a.gzero[img], 1u);
         __syncthreads();
@@ -986,6 +1020,17 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
 #pragma unroll
             for (int k = 0; k < kGhCopies; k++) v += lh[k * kGhStride + i];
             if (v) atomicAdd(&gh[i], v);
+        }
+        if (CH) {
+            uint32_t* ch = a.chist + (size_t)img * MUSICA_CLAHE_TILES * MUSICA_CLAHE_TILES * MUSICA_CLAHE_BINS;
+            for (int i = threadIdx.x; i < kChSlots * MUSICA_CLAHE_BINS; i += blockDim.x) {
+                const uint32_t slot = (uint32_t)i / MUSICA_CLAHE_BINS, tx = tx0 + (slot >> 1), ty = ty0 + (slot & 1u);
+                uint32_t v = 0u;
+#pragma unroll
+                for (int k = 0; k < kChCopies; k++) v += lc[k * kChSlots * MUSICA_CLAHE_BINS + i];
+                if (v && tx < (uint32_t)MUSICA_CLAHE_TILES && ty < (uint32_t)MUSICA_CLAHE_TILES)
+                    atomicAdd(&ch[(tx * MUSICA_CLAHE_TILES + ty) * MUSICA_CLAHE_BINS + ((uint32_t)i % MUSICA_CLAHE_BINS)], v);
+            }
         }
     }
 }
@@ -1129,7 +1174,9 @@ static void launch_expand_t(hipStream_t st, const ExpandArgs& a, int batch, bool
         const dim3 grid = stream_grid(a.S, a.Sc, a.rows_per_wave, batch);
         if (GAIN == GAIN_CURVE && NR && a.ghist) {   // level 0 with the gradation histogram on board (the caller checked cnrScale == 8)
             // W = 4: register allocation capped at 128 (4 wavefronts per SIMD, 16 dwords of scratch) against 143 registers and 3 wavefronts
-            if (a.le090) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 4, true>), grid, dim3(kBlockThreads), 0, st, a);
+            // a.chist: only with le090, a tile side (S / 4) of at least a strip and at least the rows of a workgroup (the caller checks)
+            if (a.le090 && a.chist) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 4, true, true>), grid, dim3(kBlockThreads), 0, st, a);
+            else if (a.le090) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 4, true>), grid, dim3(kBlockThreads), 0, st, a);
             else if (rows_per_trip >= 2) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 2, true>), grid, dim3(kBlockThreads), 0, st, a);
             else hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 4>), grid, dim3(kBlockThreads), 0, st, a);
         }

@@ -39,6 +39,7 @@ struct ExpandArgs {
     uint32_t* gzero;         // [batch]: set when a reconstructed texel is exactly 0 (the `return` of gradation_histogram.comp:24
                              // then cuts the scan of its 16 x 16 area short: k_grad_hist redoes that image literally)
     const uint16_t* le090;   // or: [batch][Sc][S / 8] bits of `normalized <= 0.9` written by launch_reduce_band_u16 (then raw / thr090 are not read)
+    uint32_t* chist;         // CLAHE contexts, with le090: [batch][4][4][256], the launch also counts clahe_histogram.comp (k_expand_fast<.., CH = true>)
     int swz;                 // XCD-aware tile mapping (kernels_common.h xcd_tile)
     const int* thr090;       // [batch]: largest raw value whose normalized value is <= 0.9 (k_curves_cnr)
     int ref_order;           // generic kernels: the shaders' literal 25-tap order (MUSICA_FLAG_REFERENCE_ORDER)
@@ -118,6 +119,11 @@ void launch_out_pixels(hipStream_t st, const float* graded, const LevelDesc& l0,
 void launch_copy41(hipStream_t st, const float* in, float* out, int side);
 // kernels_clahe.hip
 void launch_clahe(hipStream_t st, const float* img, const float* relevant, float* out, const LevelDesc& l0, uint32_t* hist, musica_point* pts, int batch,
-                  const uint16_t* raw = nullptr, const int* thr090 = nullptr, const float* cnr = nullptr, const LevelDesc* l3 = nullptr, int cnrScale = 0);
+                  const uint16_t* raw = nullptr, const int* thr090 = nullptr, const float* cnr = nullptr, const LevelDesc* l3 = nullptr, int cnrScale = 0,
+                  bool hist_done = false /* the histogram is already in `hist` (counted by the level-0 expand launch) */,
+                  bool with_apply = true /* false: histogram + curves only, launch_grad_clahe_apply follows */);
+// K21 + K24 in one pass (l0.S % 4 == 0): out_graded = tone curve of `curves`, out_clahe = CLAHE blend of `pts`
+void launch_grad_clahe_apply(hipStream_t st, const float* img, float* out_clahe, float* out_graded, const LevelDesc& l0, const musica_point* pts,
+                             const DevCurve* curves, int batch);
 
 }  // namespace musica

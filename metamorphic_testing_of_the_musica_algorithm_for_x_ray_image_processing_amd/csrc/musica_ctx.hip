@@ -73,6 +73,8 @@ struct musica_ctx {
     hipStream_t side1;       // dag == 1: sdev 2 beside the coarse chain
     hipEvent_t ev_s1, ev_s2;
     bool fuse_u16;           // level-0 kernels read the raw uint16 pixels; the normalized image is produced on demand only
+    bool clahe_one_apply;    // ... and whose two apply passes are one launch (MUSICA_CLAHE_ONE_APPLY=0: k_grad_apply and k_clahe_apply4)
+    bool clahe_in_expand;    // ... and whose histogram the level-0 expand launch counts (MUSICA_CLAHE_IN_EXPAND=0: k_clahe_hist)
     bool clahe_raw;          // CLAHE context whose relevant image is computed from the raw pixels (no stored normalized image)
     bool norm_valid;         // d_norm holds the normalized image of the current input
     // hipGraph replay of the two-stream dispatch (captured once per input pointer; MUSICA_FLAG_NO_GRAPH /
@@ -442,13 +444,14 @@ static musica_ctx* create_impl(const musica_params* params) {
     // order — the form for contexts whose steps run beside other contexts' steps (musica_pipeline_*): such a context
     // creates ONE stream, so that the runtime's round-robin puts consecutive contexts on different hardware queues
     // (4 by default), and nothing of a step ever waits for an event of another queue. Both forms replay a captured hipGraph.
-    // Defaults for a context that runs alone (no MUSICA_FLAG_LINEAR, i.e. not one of a pipeline's): a step whose launches are mostly
-    // smaller than their fixed cost — up to one 3072^2 image — runs fastest as eager launches on ONE stream (one 2048^2 image / L6:
-    // 0.164 ms against 0.173 for the graph replay of either form and 0.181 for eager three-stream; 1024^2: 0.121 / 0.124 - 0.131;
-    // 3072^2 / L12: 0.290 / 0.298 - 0.318): a graph node costs more than a kernel launched behind its predecessor, and the side
-    // streams' joins more than they hide. A CLAHE context keeps the three-stream form (its CLAHE block runs beside the gradation
-    // chain); larger steps keep the graph (8 x 2048^2: 4 % faster than eager) and three streams, except pyramids of 11 or more levels.
-    const bool small_step = (size_t)c->B * N * N <= (size_t)3072 * 3072 && !(params->flags & MUSICA_FLAG_CLAHE);
+    // Defaults for a context that runs alone (no MUSICA_FLAG_LINEAR, i.e. not one of a pipeline's): ONE image per step of any size,
+    // or a batch of up to 3072^2 texels, runs fastest as eager launches on ONE stream — a step is then mostly launches smaller than
+    // their fixed cost, a graph node costs more than a kernel launched behind its predecessor, and the side streams' joins cost more
+    // than they hide (ms per image, one stream eager / three streams graph / three streams eager: 2048^2 L6 + CLAHE 0.162 / 0.201 /
+    // 0.206, 4096^2 L8 0.284 / 0.303 / 0.312, 4096^2 L8 + CLAHE 0.319 / 0.348 / 0.346, 8192^2 L10 0.783 / 0.796 / 0.794; DESIGN.md
+    // section 4 has the table of the smaller sides). Larger batches keep the graph (8 x 2048^2: 4 % faster than eager) and three
+    // streams, except pyramids of 11 or more levels.
+    const bool small_step = c->B == 1 || (size_t)c->B * N * N <= (size_t)3072 * 3072;
     const bool lone = !(params->flags & MUSICA_FLAG_LINEAR);
     c->dag = (params->flags & MUSICA_FLAG_LINEAR) ? 0 : env_int("MUSICA_DAG", (L >= 11 || small_step) ? 0 : 1);
     if (c->dag < 0 || c->dag > 1) c->dag = 1;
@@ -473,6 +476,8 @@ static musica_ctx* create_impl(const musica_params* params) {
     // (a CLAHE context fuses too since its relevant image comes from the raw pixels, k_relevant4<true>; MUSICA_CLAHE_FUSE=0: as before)
     c->clahe_raw = (params->flags & MUSICA_FLAG_CLAHE) && c->fuse_u16 && (N % 4) == 0 && env_int("MUSICA_CLAHE_FUSE", 1) != 0 &&
                    (cnr_scale(c->lv[0].S, c->lv[MUSICA_CNR_LEVEL].S) % 4) == 0;
+    c->clahe_in_expand = env_int("MUSICA_CLAHE_IN_EXPAND", 1) != 0;
+    c->clahe_one_apply = env_int("MUSICA_CLAHE_ONE_APPLY", 1) != 0;
     c->fuse_gh = env_int("MUSICA_FUSE_GH", 1) != 0 && c->fuse_u16 && (!(params->flags & MUSICA_FLAG_CLAHE) || c->clahe_raw) &&
                  cnr_scale(c->lv[0].S, c->lv[MUSICA_CNR_LEVEL].S) == 8;
     ok = ok && dalloc(c, &c->d_input, B * N * N);
@@ -730,7 +735,7 @@ static ExpandArgs expand_args(musica_ctx* c, int lvl, float* dst) {
     const musica_nr_params& q = c->h_nr[lvl < 3 ? lvl : 0];
     a.lowCnr = q.lowCnr; a.lowFactor = q.lowFactor; a.highCnr = q.highCnr; a.highFactor = q.highFactor;
     a.rows_per_wave = c->rows_expand[lvl];
-    a.raw = nullptr; a.ghist = nullptr; a.gzero = nullptr; a.thr090 = nullptr; a.le090 = nullptr;
+    a.raw = nullptr; a.ghist = nullptr; a.gzero = nullptr; a.thr090 = nullptr; a.le090 = nullptr; a.chist = nullptr;
     a.swz = xcd_swizzle_on();
     a.ref_order = c->ref_order;
     return a;
@@ -738,6 +743,13 @@ static ExpandArgs expand_args(musica_ctx* c, int lvl, float* dst) {
 static int gain_mode(int lvl) { return lvl > MUSICA_CNR_LEVEL ? GAIN_CONST : (lvl == MUSICA_CNR_LEVEL ? GAIN_RANGE : GAIN_CURVE); }
 static bool uses_nr(int lvl) { return lvl < MUSICA_CNR_LEVEL - 1; }  // currentLevel < cnrLevel - 1, src/vk_processing.cpp:1009-1016
 
+// CLAHE contexts: the level-0 expand launch (rows_per_wave = rows) can also count the CLAHE histogram (k_expand_fast<.., CH>): it has
+// the `normalized <= 0.9` bits, and a workgroup's 512 columns x 8 * rows rows touch at most 2 x 2 of the 4 x 4 tiles
+static bool clahe_hist_in_expand(const musica_ctx* c, int rows) {
+    const int G = c->lv[0].S / MUSICA_CLAHE_TILES;
+    return c->d_clahe_hist && c->clahe_raw && c->fuse_gh && !c->generic && c->d_le090 && c->clahe_in_expand && (c->lv[0].S % MUSICA_CLAHE_TILES) == 0 &&
+           G >= 512 && 8 * rows <= G;
+}
 // with_hist: the level-0 launch of a fusing context also accumulates the gradation histogram (enqueue_gradation(c, true) must follow)
 static void run_expand_level_h(musica_ctx* c, int lvl, int rows, bool with_hist) {
     ExpandArgs a = expand_args(c, lvl, c->d_recon[lvl]);
@@ -745,6 +757,7 @@ static void run_expand_level_h(musica_ctx* c, int lvl, int rows, bool with_hist)
     if (with_hist && lvl == 0 && c->fuse_gh && !c->generic) {
         a.raw = c->cur_input; a.ghist = c->d_grad_hist; a.gzero = c->d_gzero; a.thr090 = c->d_thr090;
         a.le090 = c->d_le090;
+        if (clahe_hist_in_expand(c, rows)) a.chist = c->d_clahe_hist;
     }
     launch_expand(c->cur, a, gain_mode(lvl), uses_nr(lvl), c->B, c->generic, c->expand_trip);
 }
@@ -768,7 +781,9 @@ static void enqueue_gradation(musica_ctx* c, bool fused, bool beside = false) {
     const LevelDesc& l0 = c->lv[0];
     const LevelDesc& l3 = c->lv[MUSICA_CNR_LEVEL];
     const int scale = (int)cnr_scale(l0.S, l3.S);
-    beside = beside && c->d_clahe_hist && c->side && c->clahe_raw;
+    const bool ch_done = fused && clahe_hist_in_expand(c, c->rows_expand[0]);   // the level-0 expand launch counted the CLAHE histogram
+    const bool one_apply = c->d_clahe_hist && c->clahe_raw && !c->generic && (l0.S % 4) == 0 && c->clahe_one_apply;   // both curves in one pass
+    beside = beside && c->d_clahe_hist && c->side && c->clahe_raw && !(one_apply && ch_done);   // (16 curve workgroups are not worth a join)
     if (c->d_clahe_hist) {  // #ifdef ENABLE_CLAHE block, src/vk_processing.cpp:2471-2489
         hipStream_t cs = c->stream;
         if (beside) {
@@ -777,7 +792,8 @@ static void enqueue_gradation(musica_ctx* c, bool fused, bool beside = false) {
             cs = c->side;
         }
         if (c->clahe_raw) {   // relevance computed inside the histogram launch from the raw pixels: no relevant image on the hot path
-            launch_clahe(cs, c->d_recon[0], nullptr, c->d_clahe_graded, l0, c->d_clahe_hist, c->d_clahe_pts, c->B, c->cur_input, c->d_thr090, c->d_cnr, &l3, scale);
+            launch_clahe(cs, c->d_recon[0], nullptr, c->d_clahe_graded, l0, c->d_clahe_hist, c->d_clahe_pts, c->B, c->cur_input, c->d_thr090, c->d_cnr, &l3, scale,
+                         ch_done, !one_apply);
         } else {
             launch_relevant(cs, c->d_norm, c->d_cnr, c->d_scratch, l0, l3, scale, c->B);
             launch_clahe(cs, c->d_recon[0], c->d_scratch, c->d_clahe_graded, l0, c->d_clahe_hist, c->d_clahe_pts, c->B);
@@ -800,6 +816,12 @@ static void enqueue_gradation(musica_ctx* c, bool fused, bool beside = false) {
     {
         Span sp(c, MUSICA_KERNEL_GRAD_CURVE);
         launch_grad_curve(c->stream, c->d_grad_hist, c->d_grad_max, c->d_gcurve, c->B, fused ? c->d_grad_hist_b : nullptr, fused ? c->d_gzero : nullptr);
+    }
+    if (one_apply) {
+        if (beside) hipStreamWaitEvent(c->stream, c->ev_join, 0);
+        Span sp(c, MUSICA_KERNEL_GRAD_APPLY);
+        launch_grad_clahe_apply(c->stream, c->d_recon[0], c->d_clahe_graded, c->d_graded, l0, c->d_clahe_pts, c->d_gcurve, c->B);
+        return;
     }
     { Span sp(c, MUSICA_KERNEL_GRAD_APPLY); launch_grad_apply(c->stream, c->d_recon[0], c->d_graded, l0, c->d_gcurve, c->B); }
     if (beside) hipStreamWaitEvent(c->stream, c->ev_join, 0);

@@ -723,6 +723,34 @@ def test_clahe_context_with_and_without_the_raw_pixel_relevant_image(ob, fuse, m
     p.cleanup()
 
 
+@pytest.mark.parametrize("n,levels,seed,batch,in_expand,one_apply", [(2048, 6, 21, 2, "1", "1"), (2056, 6, 22, 1, "1", "1"), (3072, 7, 23, 1, "1", "1"),
+                                                                     (3072, 7, 23, 1, "0", "1"), (2048, 6, 21, 2, "1", "0"), (1024, 5, 24, 3, "1", "1")])
+def test_clahe_histogram_in_the_level0_expand_launch_and_both_curves_in_one_apply(ob, n, levels, seed, batch, in_expand, one_apply, monkeypatch):
+    """Sides whose CLAHE tile (N / 4) is at least a 512-column strip: the level-0 expand launch counts clahe_histogram.comp while the
+    texels are in registers (k_expand_fast<.., CH>) and k_clahe_hist does not run; 2056 and 3072 put tile borders inside strips
+    and inside workgroups (1024: tiles of 256 columns, the separate launch). MUSICA_CLAHE_IN_EXPAND=0 is the separate launch everywhere.
+    The tone curve and the CLAHE curves are applied in one pass over the reconstruction (k_grad_clahe_apply4; MUSICA_CLAHE_ONE_APPLY=0:
+    k_grad_apply and k_clahe_apply4). Histograms, curves and both graded images equal the oracle."""
+    monkeypatch.setenv("MUSICA_CLAHE_IN_EXPAND", in_expand)
+    monkeypatch.setenv("MUSICA_CLAHE_ONE_APPLY", one_apply)
+    px = np.stack([phantom(n, seed + k) for k in range(batch)])
+    p = _proc(n, levels, batch=batch, flags=mp.FLAG_CLAHE)
+    assert p.fuses_gradhist()
+    p.upload(px)
+    for rep in range(2):
+        assert p.execute_device(), mp.last_error()
+    p.sync()
+    for k in range(batch):
+        o = ob.Oracle(n, levels, ob.ORDER_FAST, ob.FLAG_CLAHE).execute(px[k])
+        _compare_all(p, o, ob, idx=k, tag="clahe in expand=%s image %d: " % (in_expand, k))
+        assert np.array_equal(p.clahe_hist(k), o.clahe_hist())
+        assert int(o.clahe_hist().sum()) > 0
+        a, b = p.clahe_curves(k), o.clahe_curves()
+        assert ((a == b) | (np.isnan(a) & np.isnan(b))).all()
+        _same(p.image(mp.IMG_CLAHE_GRADED, 0, k), o.image(ob.IMG_CLAHE_GRADED), "clahe graded %d" % k)
+    p.cleanup()
+
+
 @pytest.mark.parametrize("n,levels,seed,batch", [(1024, 6, 5, 1), (520, 5, 12, 3), (2048, 6, 100, 1)])
 def test_histogram_plots_equal_the_oracles(ob, n, levels, seed, batch):
     """The RENDER_HISTS plots (noise_hist_render.comp on the cnr level, gradation_curve_debug_render.comp): the HIP kernels'
