@@ -444,18 +444,20 @@ static musica_ctx* create_impl(const musica_params* params) {
     // order — the form for contexts whose steps run beside other contexts' steps (musica_pipeline_*): such a context
     // creates ONE stream, so that the runtime's round-robin puts consecutive contexts on different hardware queues
     // (4 by default), and nothing of a step ever waits for an event of another queue. Both forms replay a captured hipGraph.
-    // Defaults for a context that runs alone (no MUSICA_FLAG_LINEAR, i.e. not one of a pipeline's): ONE image per step of any size,
-    // or a batch of up to 3072^2 texels, runs fastest as eager launches on ONE stream — a step is then mostly launches smaller than
-    // their fixed cost, a graph node costs more than a kernel launched behind its predecessor, and the side streams' joins cost more
-    // than they hide (ms per image, one stream eager / three streams graph / three streams eager: 2048^2 L6 + CLAHE 0.162 / 0.201 /
-    // 0.206, 4096^2 L8 0.284 / 0.303 / 0.312, 4096^2 L8 + CLAHE 0.319 / 0.348 / 0.346, 8192^2 L10 0.783 / 0.796 / 0.794; DESIGN.md
-    // section 4 has the table of the smaller sides). Larger batches keep the graph (8 x 2048^2: 4 % faster than eager) and three
-    // streams, except pyramids of 11 or more levels.
+    // Defaults for a context that runs alone (no MUSICA_FLAG_LINEAR, i.e. not one of a pipeline's). A step of ONE image, or of a batch
+    // of up to 3072^2 texels, is mostly launches smaller than their fixed cost: a graph node costs more than a kernel launched
+    // behind its predecessor and the three-stream form's joins cost more than they hide, so it runs as eager launches on ONE stream
+    // (ms per image, one stream eager / three streams graph: 512^2 0.081 / 0.116, 1024^2 0.100 / 0.131, 2048^2 + CLAHE 0.162 / 0.201,
+    // 4096^2 0.284 / 0.303, 8192^2 0.783 / 0.796). From 2048^2 up one fork pays: the analysis launches on a second stream beside the
+    // reduce tail and the constant-gain expand slots (enqueue_fork, replayed as a graph: 2048^2 L6 0.138 against 0.142, 4096^2 L8 + CLAHE
+    // 0.306 / 0.319, 8192^2 L10 0.747 / 0.779; not for pyramids of 11 or more levels: 3072^2 L12 0.267 - 0.280 / 0.274). Larger batches keep
+    // the graph (8 x 2048^2: 4 % faster than eager) and three streams, except pyramids of 11 or more levels.
     const bool small_step = c->B == 1 || (size_t)c->B * N * N <= (size_t)3072 * 3072;
     const bool lone = !(params->flags & MUSICA_FLAG_LINEAR);
-    c->dag = (params->flags & MUSICA_FLAG_LINEAR) ? 0 : env_int("MUSICA_DAG", (L >= 11 || small_step) ? 0 : 1);
-    if (c->dag < 0 || c->dag > 1) c->dag = 1;
-    c->use_graph = !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", (lone && small_step) ? 0 : 1) != 0;
+    const bool one_big = c->B == 1 && N >= 2048 && L < 11;   // one image of 2048^2 or more: the analysis beside the tail (enqueue_fork)
+    c->dag = (params->flags & MUSICA_FLAG_LINEAR) ? 0 : env_int("MUSICA_DAG", one_big ? 2 : (L >= 11 || small_step) ? 0 : 1);
+    if (c->dag < 0 || c->dag > 2) c->dag = 1;
+    c->use_graph = !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", (lone && small_step && !one_big) ? 0 : 1) != 0;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     if (c->dag) {
         ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
@@ -696,7 +698,8 @@ static int sdev_runs_from(const musica_ctx* c) {
     while (first > 0 && c->rows_sdev[first - 1] <= 0) first--;
     return first;
 }
-static void enqueue_analysis(musica_ctx* c) {
+static void enqueue_analysis(musica_ctx* c, hipStream_t st = nullptr) {
+    if (!st) st = c->stream;
     int merged = sdev_runs_from(c);
     if (merged >= MUSICA_CNR_LEVEL) merged = MUSICA_CNR_LEVEL + 1;   // one level is its own launch
     for (int i = 0; i < merged; i++) {  // i < coarserLevelsStart || i <= cnrLevel, :2285
@@ -709,7 +712,7 @@ static void enqueue_analysis(musica_ctx* c) {
     }
     {   // curves of every level + cnr of level 3 in one launch (kernels_analysis.hip k_curves_cnr)
         Span sp(c, MUSICA_KERNEL_CURVES);
-        launch_curves_cnr(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
+        launch_curves_cnr(st, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
                           c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_thr090);
     }
 }
@@ -908,8 +911,37 @@ static void enqueue_linear(musica_ctx* c) {
     enqueue_expand(c, true);
     enqueue_gradation(c, true);
 }
+// Two streams, one fork and one join (dag == 2): the analysis (the sdev + noise-histogram launches and the curves: they read band 0 .. 3
+// and nothing of the levels above) runs on the side stream BESIDE the tail of the reduce chain and the constant-gain expand slots
+// (levels >= 4 down to expand 3: launches of a few microseconds each that read nothing the analysis writes).
+//   stream : minmax RB0 RB1 RB2 RB3 | RB4 .. RB(L-1) E(L-1) .. E3 | (wait) E2 E1 E0 gradation
+//   side   :                        | S(0..3) curves+cnr          |
+static void enqueue_fork(musica_ctx* c) {
+    const int L = c->L;
+    c->cur = c->stream;
+    enqueue_norm(c, true);
+    for (int i = 0; i <= MUSICA_CNR_LEVEL; i++) run_reduce_and_band(c, i);
+    hipEventRecord(c->ev_fork, c->stream);
+    hipStreamWaitEvent(c->side, c->ev_fork, 0);
+    c->cur = c->side;
+    enqueue_analysis(c, c->side);
+    hipEventRecord(c->ev_join, c->side);
+    c->cur = c->stream;
+    for (int i = MUSICA_CNR_LEVEL + 1; i < L; i++) run_reduce_and_band(c, i);
+    for (int lvl = L - 1; lvl >= MUSICA_CNR_LEVEL; lvl--) {
+        Span sp(c, MUSICA_KERNEL_EXPAND_REST);
+        run_expand_level(c, lvl, c->rows_expand[lvl]);
+    }
+    hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    for (int lvl = MUSICA_CNR_LEVEL - 1; lvl >= 0; lvl--) {
+        Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
+        run_expand_level(c, lvl, c->rows_expand[lvl]);
+    }
+    enqueue_gradation(c, true);
+}
 static void enqueue_script(musica_ctx* c) {
-    if (c->dag) enqueue_dag(c);
+    if (c->dag == 2) enqueue_fork(c);
+    else if (c->dag) enqueue_dag(c);
     else enqueue_linear(c);
 }
 
