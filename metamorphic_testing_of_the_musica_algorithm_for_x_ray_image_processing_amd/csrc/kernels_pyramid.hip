@@ -315,8 +315,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_u16_pf(const uint16_t*
 
 // One thread per output texel, any S >= 1. OOB loads (only reachable when S < 3, where the
 // reference's unclamped mirror() leaves the image) return 0.
+// Branch-free on purpose: the load always happens (texel (0, 0) stands in for an out-of-image tap) and the test only selects, so
+// the 25 taps of a stencil are requested together instead of one branch + load + wait each (k_tiny_tail: 41 -> 14 us).
 __device__ __forceinline__ float ld0(const float* __restrict__ im, int pitch, int S, int x, int y) {
-    return (x >= 0 && y >= 0 && x < S && y < S) ? im[(size_t)y * pitch + x] : 0.0f;
+    const bool in = x >= 0 && y >= 0 && x < S && y < S;
+    const float v = im[(size_t)(in ? y : 0) * pitch + (in ? x : 0)];
+    return in ? v : 0.0f;
 }
 
 // ---- the shaders' literal arithmetic order (MUSICA_FLAG_REFERENCE_ORDER) ---------------------------------------
@@ -338,6 +342,20 @@ __device__ __forceinline__ float smooth_literal(const float* __restrict__ in, in
     return pixel;
 }
 
+// smooth + downsample at coarse (xo, yo) for any S (generic form)
+__device__ __forceinline__ float reduce_generic_at(const float* __restrict__ in, int pitch, int S, int xo, int yo, int ref) {
+    if (ref) return smooth_literal(in, pitch, S, 2 * xo, 2 * yo);   // img_downsample.comp:15 of the literally smoothed image
+    const int hi = S - 1;
+    float v[5];
+#pragma unroll
+    for (int m = 0; m < 5; m++) {
+        const int x = mirror_idx(2 * xo + m - 2, hi);   // outside the image (S < 3): five zero taps, chain5 = +0
+        v[m] = chain5(ld0(in, pitch, S, x, mirror_idx(2 * yo - 2, hi)), ld0(in, pitch, S, x, mirror_idx(2 * yo - 1, hi)),
+                      ld0(in, pitch, S, x, mirror_idx(2 * yo, hi)), ld0(in, pitch, S, x, mirror_idx(2 * yo + 1, hi)),
+                      ld0(in, pitch, S, x, mirror_idx(2 * yo + 2, hi)));
+    }
+    return chain5(v[0], v[1], v[2], v[3], v[4]);
+}
 __global__ void k_reduce_generic(const float* __restrict__ in, float* __restrict__ out, int S, int pitch,
                                  size_t in_plane, int So, int opitch, size_t out_plane, int ref) {
     const int xo = blockIdx.x * blockDim.x + threadIdx.x;
@@ -345,21 +363,7 @@ __global__ void k_reduce_generic(const float* __restrict__ in, float* __restrict
     if (xo >= So || yo >= So) return;
     in += (size_t)blockIdx.z * in_plane;
     out += (size_t)blockIdx.z * out_plane;
-    if (ref) {   // img_downsample.comp:15 of the literally smoothed image
-        out[(size_t)yo * opitch + xo] = smooth_literal(in, pitch, S, 2 * xo, 2 * yo);
-        return;
-    }
-    const int hi = S - 1;
-    float v[5];
-#pragma unroll
-    for (int m = 0; m < 5; m++) {
-        const int x = mirror_idx(2 * xo + m - 2, hi);
-        if (x < 0 || x >= S) { v[m] = 0.0f; continue; }
-        v[m] = chain5(ld0(in, pitch, S, x, mirror_idx(2 * yo - 2, hi)), ld0(in, pitch, S, x, mirror_idx(2 * yo - 1, hi)),
-                      ld0(in, pitch, S, x, mirror_idx(2 * yo, hi)), ld0(in, pitch, S, x, mirror_idx(2 * yo + 1, hi)),
-                      ld0(in, pitch, S, x, mirror_idx(2 * yo + 2, hi)));
-    }
-    out[(size_t)yo * opitch + xo] = chain5(v[0], v[1], v[2], v[3], v[4]);
+    out[(size_t)yo * opitch + xo] = reduce_generic_at(in, pitch, S, xo, yo, ref);
 }
 
 // ======================================================================================
@@ -688,7 +692,7 @@ __device__ __forceinline__ float lowpass_generic(const float* __restrict__ coars
 #pragma unroll
             for (int n = 0; n < 5; n++) {
                 const int k = coarse_of_fine(y + n - 2, S);
-                const float tap = (j >= 0 && k >= 0) ? ld0(coarse, cpitch, Sc, j, k) : 0.0f;
+                const float tap = ld0(coarse, cpitch, Sc, j, k);   // j, k < 0 (odd fine index: the inserted zero) read 0
                 pixel = pixel + ((w5(m) * w5(n)) * 4.0f) * tap;   // :43
             }
         }
@@ -697,18 +701,14 @@ __device__ __forceinline__ float lowpass_generic(const float* __restrict__ coars
     float V[5];
 #pragma unroll
     for (int m = 0; m < 5; m++) {
-        const int j = coarse_of_fine(x + m - 2, S);
+        const int j = coarse_of_fine(x + m - 2, S);   // -1 (an inserted zero column): five zero taps, the sum is +0
         float acc = 0.0f;
-        bool first = true;
-        if (j >= 0) {
 #pragma unroll
-            for (int n = 0; n < 5; n++) {
-                const int k = coarse_of_fine(y + n - 2, S);
-                const float w = n == 0 ? W0 : n == 1 ? W1 : n == 2 ? W2 : n == 3 ? W3 : W4;
-                const float t = w * (k >= 0 ? ld0(coarse, cpitch, Sc, j, k) : 0.0f);
-                acc = first ? t : acc + t;
-                first = false;
-            }
+        for (int n = 0; n < 5; n++) {
+            const int k = coarse_of_fine(y + n - 2, S);
+            const float w = n == 0 ? W0 : n == 1 ? W1 : n == 2 ? W2 : n == 3 ? W3 : W4;
+            const float t = w * ld0(coarse, cpitch, Sc, j, k);   // j, k < 0 read 0
+            acc = n == 0 ? t : acc + t;
         }
         V[m] = acc;
     }
@@ -1088,9 +1088,99 @@ __global__ void k_exp_band_generic(ExpandArgs a) {
     a.recon[(size_t)img * a.plane + (size_t)y * a.pitch + x] = exp_band_at<GAIN, NR>(a, tab, img, x, y);
 }
 
+// ---- the tiny tail of the pyramid in one launch ------------------------------------------------------------------
+// Levels whose side is at most 32 (the last four or five of a full-depth pyramid: 24, 12, 6, 3, 2 for the reference's
+// 3072^2 / L = 12) are a few hundred texels each, yet every one costs three or four launches of ~5 us (reduce, band, expand: 14
+// launches, 72 us of a 270 us step at 3072^2 / L12). One 1024-thread workgroup per image walks them here: reduce and band of levels
+// T .. L-1, then expand L-1 .. T (constant gain: these levels are above the cnr level), a texel per thread and phase, with the
+// SAME device functions as the per-level generic launches (reduce_generic_at, lowpass_generic: same bits) and a workgroup
+// barrier between dependent phases.
+// The images live in LDS while the workgroup works on them (dense rows; ~4100 floats for sides 32, 16, 8, ..: a phase reads 25
+// taps per texel — from the XCD's L2, where the workgroup's own stores land, that is 25 round trips of ~1 us) and every result is
+// also stored to its global image (the getters, and the expand slot of level T - 1, read those).
+constexpr int kTailPool = 3 * (kTailSide * kTailSide + (kTailSide / 2) * (kTailSide / 2) * 2) + 64;   // fine + band + recon of every level (sum of squares < 1.5 x the first)
+__global__ __launch_bounds__(1024) void k_tiny_tail(const TailArgs a) {
+    __shared__ float pool[kTailPool];
+    // side of level k (k = n: the coarsest image) and where its fine, band and reconstruction images sit in the pool. Rolled
+    // loops over LDS tables on purpose: unrolled per level, the three stencils are ~100 KB of code that runs once (44 us per
+    // launch, most of it instruction fetch).
+    __shared__ int side[kTailMax + 1], offF[kTailMax + 1], offB[kTailMax], offR[kTailMax];
+    const size_t img = blockIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x, n = a.n;
+    if (tid == 0) {
+        int o = 0;
+        for (int k = 0; k <= n; k++) { side[k] = k < n ? a.l[k].S : a.Sl; offF[k] = o; o += side[k] * side[k]; }
+        for (int k = 0; k < n; k++) { offB[k] = o; o += side[k] * side[k]; offR[k] = o; o += side[k] * side[k]; }
+    }
+    {
+        const TailLevel& f = a.l[0];
+        const float* fine = f.fine + img * f.plane;
+        for (int i = tid; i < f.S * f.S; i += nt) {
+            const int y = i / f.S, x = i - y * f.S;
+            pool[i] = fine[(size_t)y * f.pitch + x];   // offF[0] = 0
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < n; k++) {
+        const int S = side[k], Sc = side[k + 1];
+        const float* fineL = pool + offF[k];
+        float* downL = pool + offF[k + 1];
+        for (int i = tid; i < Sc * Sc; i += nt) {
+            const int yo = i / Sc, xo = i - yo * Sc;
+            downL[i] = reduce_generic_at(fineL, S, S, xo, yo, a.ref);
+        }
+        __syncthreads();
+        float* bandL = pool + offB[k];
+        for (int i = tid; i < S * S; i += nt) {
+            const int y = i / S, x = i - y * S;
+            bandL[i] = fineL[i] - lowpass_generic(downL, Sc, Sc, S, x, y, a.ref);
+        }
+    }
+#pragma unroll 1
+    for (int k = n - 1; k >= 0; k--) {
+        __syncthreads();   // the coarser reconstruction is complete (and, the first time, every band image)
+        const int S = side[k], Sc = side[k + 1];
+        const float* prevL = pool + (k + 1 == n ? offF[k + 1] : offR[k + 1]);   // src/vk_processing.cpp:930-934
+        const float* bandL = pool + offB[k];
+        float* reconL = pool + offR[k];
+        const float high = a.l[k].high;
+        for (int i = tid; i < S * S; i += nt) {
+            const int y = i / S, x = i - y * S;
+            const float low = lowpass_generic(prevL, Sc, Sc, S, x, y, a.ref);
+            reconL[i] = low + bandL[i] * high;   // contrast_curve_apply.comp:61 (two-point curve), img_addition.comp:15
+        }
+    }
+    __syncthreads();
+    // every image to its global plane, once, behind the last phase
+#pragma unroll 1
+    for (int k = 0; k < n; k++) {
+        const TailLevel& f = a.l[k];
+        const bool last = k + 1 == n;
+        const int S = side[k], Sc = side[k + 1], cpitch = last ? a.lpitch : a.l[k + 1].pitch;
+        const size_t cplane = last ? a.lplane : a.l[k + 1].plane;
+        float* down = f.down + img * cplane;
+        for (int i = tid; i < Sc * Sc; i += nt) {
+            const int yo = i / Sc, xo = i - yo * Sc;
+            down[(size_t)yo * cpitch + xo] = pool[offF[k + 1] + i];
+        }
+        float* band = f.band + img * f.plane;
+        float* recon = f.recon + img * f.plane;
+        for (int i = tid; i < S * S; i += nt) {
+            const int y = i / S, x = i - y * S;
+            band[(size_t)y * f.pitch + x] = pool[offB[k] + i];
+            recon[(size_t)y * f.pitch + x] = pool[offR[k] + i];
+        }
+    }
+}
+
 // ======================================================================================
 // host-side launchers
 // ======================================================================================
+
+void launch_tiny_tail(hipStream_t st, const TailArgs& a, int batch) {
+    hipLaunchKernelGGL(k_tiny_tail, dim3(batch), dim3(1024), 0, st, a);
+}
 
 int xcd_swizzle_on() {
     static const int on = getenv("MUSICA_XCD_SWIZZLE") ? atoi(getenv("MUSICA_XCD_SWIZZLE")) : 1;

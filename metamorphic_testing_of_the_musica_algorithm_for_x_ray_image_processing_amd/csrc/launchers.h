@@ -73,6 +73,8 @@ void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, fl
                      int rows_per_wave, int rows_per_trip, const uint32_t* minmax, int min_chain_exact);
 void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch, int ref = 0);
 void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic, int rows_per_trip);
+// reduce + band of the levels in `a`, then their expand slots, one workgroup per image (levels of side <= kTailSide)
+void launch_tiny_tail(hipStream_t st, const TailArgs& a, int batch);
 void launch_exp_band(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch);
 // kernels_analysis.hip
 void launch_clear(hipStream_t st, uint32_t* minmax, uint32_t* noise_hist, uint32_t* grad_hist, uint32_t* clahe_hist, int batch, uint32_t* grad_hist_b = nullptr, uint32_t* gzero = nullptr);

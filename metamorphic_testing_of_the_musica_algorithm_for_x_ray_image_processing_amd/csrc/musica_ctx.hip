@@ -73,6 +73,7 @@ struct musica_ctx {
     hipStream_t side1;       // dag == 1: sdev 2 beside the coarse chain
     hipEvent_t ev_s1, ev_s2;
     bool fuse_u16;           // level-0 kernels read the raw uint16 pixels; the normalized image is produced on demand only
+    bool tiny_tail;          // levels of side <= kTailSide in one launch (MUSICA_TINY_TAIL=0: one launch per level and stage)
     bool clahe_one_apply;    // ... and whose two apply passes are one launch (MUSICA_CLAHE_ONE_APPLY=0: k_grad_apply and k_clahe_apply4)
     bool clahe_in_expand;    // ... and whose histogram the level-0 expand launch counts (MUSICA_CLAHE_IN_EXPAND=0: k_clahe_hist)
     bool clahe_raw;          // CLAHE context whose relevant image is computed from the raw pixels (no stored normalized image)
@@ -480,6 +481,7 @@ static musica_ctx* create_impl(const musica_params* params) {
                    (cnr_scale(c->lv[0].S, c->lv[MUSICA_CNR_LEVEL].S) % 4) == 0;
     c->clahe_in_expand = env_int("MUSICA_CLAHE_IN_EXPAND", 1) != 0;
     c->clahe_one_apply = env_int("MUSICA_CLAHE_ONE_APPLY", 1) != 0;
+    c->tiny_tail = env_int("MUSICA_TINY_TAIL", 1) != 0;
     c->fuse_gh = env_int("MUSICA_FUSE_GH", 1) != 0 && c->fuse_u16 && (!(params->flags & MUSICA_FLAG_CLAHE) || c->clahe_raw) &&
                  cnr_scale(c->lv[0].S, c->lv[MUSICA_CNR_LEVEL].S) == 8;
     ok = ok && dalloc(c, &c->d_input, B * N * N);
@@ -671,6 +673,39 @@ static void run_sdev_level(musica_ctx* c, int i, int rows) {
                      (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov, c->B, rows);
 }
 
+// The first level of the tiny tail (k_tiny_tail: reduce + band of levels T .. L-1 and their expand slots in one launch), L if none:
+// levels above the cnr level whose side is at most kTailSide, where there are at least two of them (a lone level is two launches
+// either way). The whole-step scripts use it; the stage entry points (debug_stage) keep one launch per level and stage.
+static int tail_first(const musica_ctx* c) {
+    if (!c->tiny_tail) return c->L;
+    int T = c->L;
+    while (T - 1 > MUSICA_CNR_LEVEL && c->lv[T - 1].S <= kTailSide) T--;
+    if (c->L - T > kTailMax) T = c->L - kTailMax;
+    return c->L - T >= 2 ? T : c->L;
+}
+static void run_tiny_tail(musica_ctx* c, int T) {
+    TailArgs a;
+    a.n = c->L - T;
+    for (int k = 0; k < a.n; k++) {
+        const int i = T + k;
+        a.l[k] = TailLevel{level_input(c, i), c->d_down[i], c->d_band[i], c->d_recon[i], c->lv[i].plane, c->lv[i].S, c->lv[i].pitch,
+                           c->h_cparams[i].highContrastFactor};
+    }
+    for (int k = a.n; k < kTailMax; k++) a.l[k] = a.l[0];
+    a.Sl = c->lv[c->L].S; a.lpitch = c->lv[c->L].pitch; a.lplane = c->lv[c->L].plane;
+    a.ref = c->ref_order;
+    Span sp(c, MUSICA_KERNEL_REDUCE_REST);
+    launch_tiny_tail(c->cur, a, c->B);
+}
+// reduce + band of levels first .. L-1 and, with the tiny tail, the expand slots of its levels; returns the first level whose
+// expand slot is still to run (L: none)
+static int enqueue_reduce_from(musica_ctx* c, int first) {
+    const int T = tail_first(c);
+    for (int i = first; i < T; i++) run_reduce_and_band(c, i);
+    if (T < c->L) run_tiny_tail(c, T);
+    return T;
+}
+
 // stage "red" (src/vk_processing.cpp:2233-2273)
 static void enqueue_reduce(musica_ctx* c) {
     for (int i = 0; i < c->L; i++) run_reduce_and_band(c, i);
@@ -767,8 +802,8 @@ static void run_expand_level_h(musica_ctx* c, int lvl, int rows, bool with_hist)
 static void run_expand_level(musica_ctx* c, int lvl, int rows) { run_expand_level_h(c, lvl, rows, true); }
 
 // stages "aply" + "exp" (src/vk_processing.cpp:2361-2431)
-static void enqueue_expand(musica_ctx* c, bool with_hist) {
-    for (int lvl = c->L - 1; lvl >= 0; lvl--) {
+static void enqueue_expand(musica_ctx* c, bool with_hist, int top = -1 /* first slot to run, default L - 1 */) {
+    for (int lvl = top < 0 ? c->L - 1 : top; lvl >= 0; lvl--) {
         Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
         run_expand_level_h(c, lvl, c->rows_expand[lvl], with_hist);
     }
@@ -854,7 +889,6 @@ static void enqueue_gradation(musica_ctx* c, bool fused, bool beside = false) {
 // image for the whole tail of levels >= 3 (bit-exact, but 153 us for one image — a single CU walks it row by row — against
 // ~100 us for the ten launches it replaces).
 static void enqueue_dag(musica_ctx* c) {
-    const int L = c->L;
     c->cur = c->stream;
     enqueue_norm(c, true);   // with the clears of :2153-2162
     // reduce (+ band, where the fused march applies: k_reduce_band) of levels 0 and 1
@@ -878,8 +912,8 @@ static void enqueue_dag(musica_ctx* c) {
     { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, 2, c->rows_sdev[2]); }
     hipEventRecord(c->ev_s1, c->side1);
     c->cur = c->side;
-    for (int i = MUSICA_CNR_LEVEL + 1; i < L; i++) run_reduce_and_band(c, i);
-    for (int lvl = L - 1; lvl > MUSICA_CNR_LEVEL; lvl--) {
+    const int T = enqueue_reduce_from(c, MUSICA_CNR_LEVEL + 1);
+    for (int lvl = T - 1; lvl > MUSICA_CNR_LEVEL; lvl--) {
         Span sp(c, MUSICA_KERNEL_EXPAND_REST);
         run_expand_level(c, lvl, c->rows_expand[lvl]);
     }
@@ -906,9 +940,9 @@ static void enqueue_dag(musica_ctx* c) {
 static void enqueue_linear(musica_ctx* c) {
     c->cur = c->stream;
     enqueue_norm(c, true);   // with the clears of :2153-2162
-    enqueue_reduce(c);
+    const int T = enqueue_reduce_from(c, 0);
     enqueue_analysis(c);
-    enqueue_expand(c, true);
+    enqueue_expand(c, true, T - 1);
     enqueue_gradation(c, true);
 }
 // Two streams, one fork and one join (dag == 2): the analysis (the sdev + noise-histogram launches and the curves: they read band 0 .. 3
@@ -917,7 +951,6 @@ static void enqueue_linear(musica_ctx* c) {
 //   stream : minmax RB0 RB1 RB2 RB3 | RB4 .. RB(L-1) E(L-1) .. E3 | (wait) E2 E1 E0 gradation
 //   side   :                        | S(0..3) curves+cnr          |
 static void enqueue_fork(musica_ctx* c) {
-    const int L = c->L;
     c->cur = c->stream;
     enqueue_norm(c, true);
     for (int i = 0; i <= MUSICA_CNR_LEVEL; i++) run_reduce_and_band(c, i);
@@ -927,8 +960,8 @@ static void enqueue_fork(musica_ctx* c) {
     enqueue_analysis(c, c->side);
     hipEventRecord(c->ev_join, c->side);
     c->cur = c->stream;
-    for (int i = MUSICA_CNR_LEVEL + 1; i < L; i++) run_reduce_and_band(c, i);
-    for (int lvl = L - 1; lvl >= MUSICA_CNR_LEVEL; lvl--) {
+    const int T = enqueue_reduce_from(c, MUSICA_CNR_LEVEL + 1);
+    for (int lvl = T - 1; lvl >= MUSICA_CNR_LEVEL; lvl--) {
         Span sp(c, MUSICA_KERNEL_EXPAND_REST);
         run_expand_level(c, lvl, c->rows_expand[lvl]);
     }

@@ -93,6 +93,25 @@ struct SdevRunLevels {
     int n;
 };
 
+// the levels of one k_tiny_tail launch (kernels_pyramid.hip): level T + k reads `fine`, writes its reduced image `down`, its
+// band-pass image and its reconstruction; Sl / lpitch / lplane: the geometry of the last level's `down` (the coarsest image)
+constexpr int kTailMax = 8;
+constexpr int kTailSide = 32;   // finest level the tail takes
+struct TailLevel {
+    const float* fine;
+    float* down;
+    float* band;
+    float* recon;
+    size_t plane;
+    int S, pitch;
+    float high;   // highContrastFactor of the level (GAIN_CONST)
+};
+struct TailArgs {
+    TailLevel l[kTailMax];
+    size_t lplane;
+    int n, Sl, lpitch, ref;
+};
+
 static inline int round_up4(int v) { return (v + 3) & ~3; }
 
 }  // namespace musica

@@ -723,6 +723,28 @@ def test_clahe_context_with_and_without_the_raw_pixel_relevant_image(ob, fuse, m
     p.cleanup()
 
 
+@pytest.mark.parametrize("n,levels,batch,tail,dag", [(3072, 0, 1, "1", None), (3072, 0, 1, "0", None), (1000, 0, 2, "1", None), (333, 0, 1, "1", None),
+                                                     (2048, 0, 2, "1", "1"), (2048, 0, 1, "1", "2"), (4096, 0, 1, "1", None)])
+def test_tiny_tail_of_a_full_depth_pyramid_in_one_launch(ob, n, levels, batch, tail, dag, monkeypatch):
+    """levels = 0 is the reference's own call (full depth: 12 levels at 3072^2). The levels of side <= 32 — reduce, band and expand of
+    each, 14 launches at 3072^2 — run as ONE launch of one workgroup per image (k_tiny_tail) in every dispatch form; MUSICA_TINY_TAIL=0
+    is one launch per level and stage. Every image of every level equals the oracle either way."""
+    monkeypatch.setenv("MUSICA_TINY_TAIL", tail)
+    if dag is not None:
+        monkeypatch.setenv("MUSICA_DAG", dag)
+    px = np.stack([phantom(n, 40 + k) for k in range(batch)])
+    p = _proc(n, levels, batch=batch)
+    p.upload(px)
+    for rep in range(2):
+        assert p.execute_device(), mp.last_error()
+    p.sync()
+    for k in range(batch):
+        o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[k])
+        assert p.pyramidLevels == o.levels
+        _compare_all(p, o, ob, idx=k, tag="tiny tail=%s %d image %d: " % (tail, n, k))
+    p.cleanup()
+
+
 @pytest.mark.parametrize("n,levels,seed,batch,in_expand,one_apply", [(2048, 6, 21, 2, "1", "1"), (2056, 6, 22, 1, "1", "1"), (3072, 7, 23, 1, "1", "1"),
                                                                      (3072, 7, 23, 1, "0", "1"), (2048, 6, 21, 2, "1", "0"), (1024, 5, 24, 3, "1", "1")])
 def test_clahe_histogram_in_the_level0_expand_launch_and_both_curves_in_one_apply(ob, n, levels, seed, batch, in_expand, one_apply, monkeypatch):
