@@ -8,7 +8,7 @@ noise-reduction + expand -> gradation) over one batch of synthetic raw images al
 HBM. Steps alternate over --in-flight contexts (default 3, the C ABI's musica_pipeline_*: step s is enqueued on context s mod 3, each
 context with its own copy of the input, its own buffers and ONE in-order stream, so the chip-filling kernels of a step
 run in the part-idle phases of the two steps beside it); `one_context` in the JSON line is the same K steps on a single
-three-stream context, each step behind the previous one. After the W warm-up steps the whole job (the same K steps + its
+context with the library's default dispatch for that batch (its `what` names it), each step behind the previous one. After the W warm-up steps the whole job (the same K steps + its
 tail) is rehearsed once, untimed; the timed region is then EXACTLY K steps between a barrier + device synchronize on both
 sides. Default workload C4 is BASELINE.json configs[3] seen from one GPU:
 8 independent 2048 x 2048 16-bit images, 6-level pyramid, per GPU and per step (weak scaling: at N = 8
@@ -251,7 +251,7 @@ def main():
     queue_calibration = {str(k): round(v, 4) for k, v in pipe.calibration().items()} or None
     if depth == 1:
         proc = pipe.context(0)
-    else:                                                          # the per-kernel passes and the other measurements: one default (three-stream) context
+    else:                                                          # the per-kernel passes and the other measurements: one context alone, default dispatch
         proc = mp.MusicaProcessing(device=local_rank)
         if not proc.init(n, levels=levels, batch=batch, flags=flags):
             raise SystemExit("musica_create failed: " + mp.last_error())
@@ -482,7 +482,7 @@ def main():
                 p1.sync()
                 ts = (time.perf_counter() - ts0) / args.steps
                 single = {"workload": "1 x %dx%d per execute, %d-level pyramid (BASELINE configs[1] shape)" % (n, n, levels),
-                          "value": round(n * n / 1e6 / ts, 1), "unit": "MP/s", "ms_per_image": round(ts * 1e3, 4)}
+                          "value": round(n * n / 1e6 / ts, 1), "unit": "MP/s", "ms_per_image": round(ts * 1e3, 4), "dispatch": p1.dispatch_text()}
                 p1.cleanup()
         # The reference's own call shape and the drop-in itself: one 3072 x 3072 image, L = 12 (test/standalone/main.cpp:31,
         # src/vk_processing.cpp:1989). (a) one context, one image per execute, resident input; (b) `musica-standalone <raw> <bmp>` as
@@ -511,7 +511,7 @@ def main():
                 tr_host = (time.perf_counter() - tr0) / 3
                 ref = {"workload": "1 x 3072x3072 per execute, 12-level pyramid (the reference's configuration), one context",
                        "ms_per_image_resident_input": round(tr_dev * 1e3, 4), "MPps_resident_input": round(rn * rn / 1e6 / tr_dev, 1),
-                       "ms_per_image_host_input_synchronous": round(tr_host * 1e3, 4)}
+                       "ms_per_image_host_input_synchronous": round(tr_host * 1e3, 4), "dispatch": pr.dispatch_text()}
                 pr.cleanup()
             with tempfile.TemporaryDirectory() as td:
                 from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.phantom import write_raw
@@ -594,7 +594,7 @@ def main():
                       "Parity with the reference itself is unpinned (no vectors in the reference, GLSL not buildable here)",
             "roofline": roofline, "roofline_4096_warm": warm, "roofline_pipeline_l0": pipeline_l0, "cpu_baseline": cpu, "kernels": kernels,
             "one_context": {"ms_per_step": round(one_ctx_ms, 4), "value": round(batch * n * n / 1e6 / (one_ctx_ms * 1e-3), 1), "unit": "MP/s per GPU",
-                            "what": "the same %d steps on one three-stream context, each step behind the previous one (rank 0)" % args.steps},
+                            "what": "the same %d steps on one context alone (%s), each step behind the previous one (rank 0)" % (args.steps, proc.dispatch_text())},
             "e2e_host_MPps": round(e2e, 1),
             "e2e_host_overlapped": {"value": round(e2e_stream, 1), "unit": "MP/s", "what": "musica_execute_stream over %d batches in pinned host memory: H2D of batch j+1 under the kernels of batch j (PCIe-inclusive; never `value`)" % reps,
                                     "pcie_bound_MPps": round(63e9 / 2 / 1e6, 1), "fraction_of_device_rate": round(e2e_stream / (mpix / elapsed), 3)},

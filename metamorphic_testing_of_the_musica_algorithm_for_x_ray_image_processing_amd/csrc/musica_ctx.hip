@@ -450,20 +450,24 @@ static musica_ctx* create_impl(const musica_params* params) {
     // behind its predecessor and the three-stream form's joins cost more than they hide, so it runs as eager launches on ONE stream
     // (ms per image, one stream eager / three streams graph: 512^2 0.081 / 0.116, 1024^2 0.100 / 0.131, 2048^2 + CLAHE 0.162 / 0.201,
     // 4096^2 0.284 / 0.303, 8192^2 0.783 / 0.796). From 2048^2 up one fork pays: the analysis launches on a second stream beside the
-    // reduce tail and the constant-gain expand slots (enqueue_fork, replayed as a graph: 2048^2 L6 0.138 against 0.142, 4096^2 L8 + CLAHE
-    // 0.306 / 0.319, 8192^2 L10 0.747 / 0.779; not for pyramids of 11 or more levels: 3072^2 L12 0.267 - 0.280 / 0.274). Larger batches keep
+    // reduce tail and the constant-gain expand slots (enqueue_fork; replayed as a graph: 2048^2 L6 0.138 against 0.142, 4096^2 L8 + CLAHE
+    // 0.306 / 0.319, 8192^2 L10 0.747 / 0.779; eager for pyramids of 11 or more levels: 3072^2 L12 0.214 / 0.240, 4096^2 L12 0.277 / 0.308). Larger batches keep
     // the graph (8 x 2048^2: 4 % faster than eager) and three streams, except pyramids of 11 or more levels.
     const bool small_step = c->B == 1 || (size_t)c->B * N * N <= (size_t)3072 * 3072;
     const bool lone = !(params->flags & MUSICA_FLAG_LINEAR);
-    const bool one_big = c->B == 1 && N >= 2048 && L < 11;   // one image of 2048^2 or more: the analysis beside the tail (enqueue_fork)
+    // (not for one-shot use — no autotune, no graph: musica-standalone — where creating the second stream costs more than it saves)
+    const bool one_shot = (params->flags & MUSICA_FLAG_NO_AUTOTUNE) && (params->flags & MUSICA_FLAG_NO_GRAPH);
+    const bool one_big = c->B == 1 && N >= 2048 && !one_shot;   // one image of 2048^2 or more: the analysis beside the tail (enqueue_fork)
     c->dag = (params->flags & MUSICA_FLAG_LINEAR) ? 0 : env_int("MUSICA_DAG", one_big ? 2 : (L >= 11 || small_step) ? 0 : 1);
     if (c->dag < 0 || c->dag > 2) c->dag = 1;
-    c->use_graph = !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", (lone && small_step && !one_big) ? 0 : 1) != 0;
+    c->use_graph = !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", (lone && small_step && !(one_big && L < 11)) ? 0 : 1) != 0;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     if (c->dag) {
         ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+    }
+    if (c->dag == 1) {
         ok = ok && hipStreamCreateWithFlags(&c->side1, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->ev_s1, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->ev_s2, hipEventDisableTiming) == hipSuccess;
@@ -557,6 +561,12 @@ static musica_ctx* create_impl(const musica_params* params) {
 uint32_t musica_get_image_size(const musica_ctx* c) { return c ? (uint32_t)c->N : 0; }
 uint32_t musica_get_levels(const musica_ctx* c) { return c ? (uint32_t)c->L : 0; }
 uint32_t musica_get_batch(const musica_ctx* c) { return c ? (uint32_t)c->B : 0; }
+int musica_get_dispatch(const musica_ctx* c, int* streams, int* graph) {
+    if (!c) return 0;
+    if (streams) *streams = c->dag == 0 ? 1 : c->dag == 2 ? 2 : 3;
+    if (graph) *graph = c->use_graph ? 1 : 0;
+    return 1;
+}
 int musica_fuses_gradation_histogram(const musica_ctx* c) { return (c && c->fuse_gh && !c->generic) ? 1 : 0; }
 int musica_fuses_reduce_band(const musica_ctx* c) { return (c && rb_level(c, 0)) ? 1 : 0; }
 uint32_t musica_get_level_size(const musica_ctx* c, uint32_t level) { return (c && (int)level <= c->L) ? (uint32_t)c->lv[level].S : 0; }

@@ -105,6 +105,7 @@ ABI = {
     "musica_get_level_size": (C.c_uint32, [_VP, C.c_uint32]),
     "musica_fuses_gradation_histogram": (C.c_int, [_VP]),
     "musica_fuses_reduce_band": (C.c_int, [_VP]),
+    "musica_get_dispatch": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "musica_execute": (C.c_int, [_VP, _U16P]),
     "musica_execute_device": (C.c_int, [_VP, _VP]),
     "musica_execute_stream": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, C.POINTER(Stats)]),
@@ -425,6 +426,17 @@ class MusicaProcessing:
         out = np.empty((4, 4, 256, 2), dtype=np.float32)
         self._ok(self._lib.musica_get_clahe_curves(self._h, image_index, C.cast(out.ctypes.data, C.POINTER(Point))), "musica_get_clahe_curves")
         return out
+
+    def dispatch(self):
+        """(streams, graph): 1 / 2 / 3 streams and whether steps replay a captured hipGraph (musica_get_dispatch)."""
+        st, g = C.c_int(0), C.c_int(0)
+        self._lib.musica_get_dispatch(self._h, C.byref(st), C.byref(g))
+        return st.value, bool(g.value)
+
+    def dispatch_text(self):
+        st, g = self.dispatch()
+        return "%s, %s" % ({1: "one stream", 2: "two streams (analysis beside the reduce tail)", 3: "three streams"}[st],
+                           "hipGraph replay" if g else "eager launches")
 
     def fuses_gradhist(self):
         """True when the level-0 expand kernel also accumulates the gradation histogram (no separate k_grad_hist launch)."""
