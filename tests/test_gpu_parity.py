@@ -175,17 +175,35 @@ def test_image_groups_give_the_same_bits(ob, flags, monkeypatch):
     grp.cleanup()
 
 
+def test_default_dispatch_per_workload(monkeypatch):
+    """What musica_create picks when nothing overrides it: one image below 2048^2 and small batches: one stream,
+    eager; one image of 2048^2 or more: two streams (graph replay below 11 levels); larger batches: three streams + graph; pipeline
+    contexts (MUSICA_FLAG_LINEAR): one stream + graph; one-shot contexts (the CLI's flags): one stream, eager."""
+    for v in ("MUSICA_DAG", "MUSICA_GRAPH"):
+        monkeypatch.delenv(v, raising=False)
+    cases = [((512, 4, 1, 0), (1, False)), ((1024, 5, 4, 0), (1, False)), ((2048, 6, 1, 0), (2, True)), ((2048, 0, 1, 0), (2, False)),
+             ((2048, 6, 8, 0), (3, True)), ((2048, 6, 8, mp.FLAG_LINEAR), (1, True)), ((2048, 6, 1, mp.FLAG_NO_AUTOTUNE | mp.FLAG_NO_GRAPH), (1, False)),
+             ((4096, 8, 1, mp.FLAG_CLAHE), (2, True))]
+    for (n, levels, batch, flags), want in cases:
+        p = _proc(n, levels, batch=batch, flags=flags)
+        assert p.dispatch() == want, (n, levels, batch, flags, p.dispatch_text())
+        p.cleanup()
+
+
 @pytest.mark.parametrize("batch", [1, 3])
 def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
-    """MUSICA_DAG = 0 (one in-order stream, the reference's order) and 1 (three streams), graph replay and eager:
-    every form against the oracle, twice in a row (histograms re-cleared, events re-armed)."""
+    """MUSICA_DAG = 0 (one in-order stream, the reference's order), 1 (three streams) and 2 (two streams: the analysis beside the
+    reduce tail), graph replay and eager: every form against the oracle, twice in a row (histograms re-cleared, events re-armed),
+    and musica_get_dispatch reports the form."""
     n, levels = 1032, 6
     px = np.stack([phantom(n, 800 + k) for k in range(batch)])
     want = [ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[k]) for k in range(batch)]
-    for dag in ("0", "1"):
-        for flags in (0, mp.FLAG_NO_GRAPH):
+    for dag in ("0", "1", "2"):
+        for flags, graph in ((0, "1"), (mp.FLAG_NO_GRAPH, "1"), (0, "0")):
             monkeypatch.setenv("MUSICA_DAG", dag)
+            monkeypatch.setenv("MUSICA_GRAPH", graph)
             p = _proc(n, levels, batch=batch, flags=flags)
+            assert p.dispatch() == ({"0": 1, "1": 3, "2": 2}[dag], flags == 0 and graph == "1")
             for rep in range(2):
                 assert p.execute(px)
             for k in range(batch):
