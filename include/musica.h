@@ -99,9 +99,9 @@ typedef struct musica_stats {
 #define MUSICA_FLAG_CLAHE      0x1u /* CLAHE gradation (reference: #ifdef ENABLE_CLAHE, vk_processing.h:13) */
 #define MUSICA_FLAG_NO_GRAPH   0x2u /* launch kernels eagerly instead of replaying a captured hipGraph */
 #define MUSICA_FLAG_GENERIC_KERNELS 0x4u /* test hook: use the one-thread-per-texel kernels at every level */
-#define MUSICA_FLAG_LINEAR     0x10u /* one in-order stream in the reference's submission order (src/vk_processing.cpp:2104-2601) instead of the
-                                        three-stream form: for contexts that run beside other contexts on one GPU (each then owns one
-                                        stream = one hardware queue; 4 such contexts with alternating steps: +15 % throughput) */
+#define MUSICA_FLAG_LINEAR     0x10u /* one in-order stream in the reference's submission order (src/vk_processing.cpp:2104-2601), replayed as a
+                                        graph, whatever the workload: for contexts that run beside other contexts on one GPU (each then owns
+                                        one stream = one hardware queue; musica_pipeline_* alternates steps over three of them) */
 #define MUSICA_FLAG_NO_AUTOTUNE 0x8u /* skip the init-time launch-geometry autotune (rows per wavefront stay heuristic) */
 #define MUSICA_FLAG_REFERENCE_ORDER 0x20u /* the shaders' literal arithmetic order: img_smooth.comp:32-45, img_smooth_upsampled.comp:32-45
                                         (with the * 4.0 per tap) and img_sdev.comp:17-30 accumulate their 25 taps m (x) outer,
@@ -179,7 +179,7 @@ int musica_fuses_reduce_band(const musica_ctx* ctx);
 uint32_t musica_get_level_size(const musica_ctx* ctx, uint32_t level);
 /* How this context dispatches a step (chosen by musica_create from the batch, the image side, the depth of the pyramid and the
  * flags): *streams = 1 (the reference's one in-order queue), 2 (the analysis launches on a second stream
- * beside the reduce tail) or 3 (the three-stream script of batches); *graph = 1 when steps replay a captured hipGraph, 0 for
+ * beside the reduce tail: the default for everything but small steps) or 3 (the three-stream script, MUSICA_DAG=1); *graph = 1 when steps replay a captured hipGraph, 0 for
  * eager launches. Either pointer may be NULL. Returns 1, 0 for a NULL context. */
 int musica_get_dispatch(const musica_ctx* ctx, int* streams, int* graph);
 

@@ -440,27 +440,28 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->grad_groups = 1;
 
     const size_t B = (size_t)c->B;
-    // 1: the three-stream form (enqueue_dag), the fastest for a context that has the GPU to itself (one 2048^2 image 0.204 vs
-    // 0.215 ms, 8 x 2048^2 0.484 vs 0.496 ms); 0 (MUSICA_FLAG_LINEAR, or MUSICA_DAG=0): one in-order stream in the reference's
-    // order — the form for contexts whose steps run beside other contexts' steps (musica_pipeline_*): such a context
-    // creates ONE stream, so that the runtime's round-robin puts consecutive contexts on different hardware queues
-    // (4 by default), and nothing of a step ever waits for an event of another queue. Both forms replay a captured hipGraph.
-    // Defaults for a context that runs alone (no MUSICA_FLAG_LINEAR, i.e. not one of a pipeline's). A step of ONE image, or of a batch
-    // of up to 3072^2 texels, is mostly launches smaller than their fixed cost: a graph node costs more than a kernel launched
-    // behind its predecessor and the three-stream form's joins cost more than they hide, so it runs as eager launches on ONE stream
-    // (ms per image, one stream eager / three streams graph: 512^2 0.081 / 0.116, 1024^2 0.100 / 0.131, 2048^2 + CLAHE 0.162 / 0.201,
-    // 4096^2 0.284 / 0.303, 8192^2 0.783 / 0.796). From 2048^2 up one fork pays: the analysis launches on a second stream beside the
-    // reduce tail and the constant-gain expand slots (enqueue_fork; replayed as a graph: 2048^2 L6 0.138 against 0.142, 4096^2 L8 + CLAHE
-    // 0.306 / 0.319, 8192^2 L10 0.747 / 0.779; eager for pyramids of 11 or more levels: 3072^2 L12 0.214 / 0.240, 4096^2 L12 0.277 / 0.308). Larger batches keep
-    // the graph (8 x 2048^2: 4 % faster than eager) and three streams, except pyramids of 11 or more levels.
-    const bool small_step = c->B == 1 || (size_t)c->B * N * N <= (size_t)3072 * 3072;
+    // How a step is dispatched (DESIGN.md section 4 has the measurements behind every line; musica_get_dispatch reports the choice):
+    //  * MUSICA_FLAG_LINEAR: ONE in-order stream in the reference's order, replayed as a graph — the form for contexts whose steps
+    //    run beside other contexts' steps (musica_pipeline_*): such a context creates one stream, so that the runtime's round-robin
+    //    puts consecutive contexts on different hardware queues (4 by default) and nothing of a step waits for another queue;
+    //  * a context that runs alone with a small step — one image below 2048^2, or a batch of up to 3072^2 texels — is mostly
+    //    launches smaller than their fixed cost: eager launches on one stream (a graph node costs more than a kernel launched behind
+    //    its predecessor, a cross-stream join more than it hides: 512^2 0.081 ms against 0.116 for three streams + graph, 1024^2
+    //    0.100 / 0.131, 8 x 1024^2 0.170 / 0.196, 2 x 2048^2 0.180 / 0.207);
+    //  * everything larger: TWO streams (enqueue_fork: the analysis launches beside the reduce tail and the constant-gain expand
+    //    slots, one fork and one join), replayed as a graph (2048^2 L6 0.138 against 0.142 on one stream, 4096^2 L8 + CLAHE 0.306 /
+    //    0.319, 8192^2 L10 0.747 / 0.779, 4 x 2048^2 0.264 / 0.263 (three streams: 0.287), 2 x 4096^2 0.433 / 0.457 (0.451), 8 x 2048^2
+    //    0.434 / 0.443 (0.431)); one image with a pyramid of 11 or more levels: eager (3072^2 L12 0.214 against 0.220 as a graph and
+    //    0.240 on one stream, 4096^2 L12 0.277 / 0.292 / 0.308);
+    //  * one-shot contexts (MUSICA_FLAG_NO_AUTOTUNE | MUSICA_FLAG_NO_GRAPH: musica-standalone): one stream — creating a second one
+    //    costs more than one step saves;
+    //  * MUSICA_DAG=1: the three-stream form (enqueue_dag), the default for batches until round 3; never the default now.
     const bool lone = !(params->flags & MUSICA_FLAG_LINEAR);
-    // (not for one-shot use — no autotune, no graph: musica-standalone — where creating the second stream costs more than it saves)
     const bool one_shot = (params->flags & MUSICA_FLAG_NO_AUTOTUNE) && (params->flags & MUSICA_FLAG_NO_GRAPH);
-    const bool one_big = c->B == 1 && N >= 2048 && !one_shot;   // one image of 2048^2 or more: the analysis beside the tail (enqueue_fork)
-    c->dag = (params->flags & MUSICA_FLAG_LINEAR) ? 0 : env_int("MUSICA_DAG", one_big ? 2 : (L >= 11 || small_step) ? 0 : 1);
-    if (c->dag < 0 || c->dag > 2) c->dag = 1;
-    c->use_graph = !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", (lone && small_step && !(one_big && L < 11)) ? 0 : 1) != 0;
+    const bool small_step = c->B == 1 ? N < 2048 : (size_t)c->B * N * N <= (size_t)3072 * 3072;
+    c->dag = !lone ? 0 : env_int("MUSICA_DAG", (small_step || one_shot) ? 0 : 2);
+    if (c->dag < 0 || c->dag > 2) c->dag = 2;
+    c->use_graph = !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", (lone && (small_step || (c->B == 1 && L >= 11))) ? 0 : 1) != 0;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     if (c->dag) {
         ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;

@@ -176,13 +176,13 @@ def test_image_groups_give_the_same_bits(ob, flags, monkeypatch):
 
 
 def test_default_dispatch_per_workload(monkeypatch):
-    """What musica_create picks when nothing overrides it: one image below 2048^2 and small batches: one stream,
-    eager; one image of 2048^2 or more: two streams (graph replay below 11 levels); larger batches: three streams + graph; pipeline
+    """What musica_create picks when nothing overrides it: one image below 2048^2 and batches of up to 3072^2
+    texels: one stream, eager; everything larger: two streams, graph replay (eager for one image with 11 or more levels); pipeline
     contexts (MUSICA_FLAG_LINEAR): one stream + graph; one-shot contexts (the CLI's flags): one stream, eager."""
     for v in ("MUSICA_DAG", "MUSICA_GRAPH"):
         monkeypatch.delenv(v, raising=False)
     cases = [((512, 4, 1, 0), (1, False)), ((1024, 5, 4, 0), (1, False)), ((2048, 6, 1, 0), (2, True)), ((2048, 0, 1, 0), (2, False)),
-             ((2048, 6, 8, 0), (3, True)), ((2048, 6, 8, mp.FLAG_LINEAR), (1, True)), ((2048, 6, 1, mp.FLAG_NO_AUTOTUNE | mp.FLAG_NO_GRAPH), (1, False)),
+             ((2048, 6, 8, 0), (2, True)), ((2048, 6, 2, 0), (1, False)), ((2048, 0, 8, 0), (2, True)), ((2048, 6, 8, mp.FLAG_LINEAR), (1, True)), ((2048, 6, 1, mp.FLAG_NO_AUTOTUNE | mp.FLAG_NO_GRAPH), (1, False)),
              ((4096, 8, 1, mp.FLAG_CLAHE), (2, True))]
     for (n, levels, batch, flags), want in cases:
         p = _proc(n, levels, batch=batch, flags=flags)
