@@ -23,12 +23,10 @@ namespace musica {
 // RAW: `normalized <= 0.9` (img_relevant.comp:56) is tested on the raw uint16 pixel against the per-image
 // threshold norm_threshold_090() — exact, because the normalisation is monotone — so the kernel reads
 // 2 B/px of raw input instead of a stored 4 B/px normalized image.
+// The body works for any workgroup of whole wavefronts: blockDim.x / 64 wavefronts side by side (256 columns each).
 template <bool SHARED8, bool RAW>
-__global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
-    __shared__ uint32_t lh[MUSICA_GRAD_BINS + 64];  // + one scratch word per lane for the branch-free adds
-    __shared__ int s_thr;
-    const int img = blockIdx.z;
-    if (a.only_if && a.only_if[img] == 0u) return;   // block-uniform: nothing to redo for this image
+__device__ __forceinline__ void grad_hist_body(const GradArgs& a, int img, uint32_t* lh /* [MUSICA_GRAD_BINS + 64] */, int& s_thr) {
+    const int waves_per_block = (int)(blockDim.x >> 6);
     for (int i = threadIdx.x; i < MUSICA_GRAD_BINS + 64; i += blockDim.x) lh[i] = 0u;
     if (RAW && threadIdx.x == 0) {
         float minv, maxv;
@@ -45,7 +43,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
     const int N = a.N;
     // the four wavefronts of a workgroup sit side by side (1024 columns x 16 rows per group): a workgroup reads 4 KiB
     // of every row it touches instead of four separate 1 KiB pieces
-    const int c = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 256 + lane * 4;
+    const int c = (blockIdx.x * waves_per_block + (threadIdx.x >> 6)) * 256 + lane * 4;
     const int valid = min(max(N - c, 0), 4);                  // in-image columns among the lane's 4
     const uint32_t coff = c < N ? (uint32_t)c * 4u : kOob;
     const uint32_t rb = (uint32_t)a.pitch * 4u, crb = (uint32_t)a.cnrPitch * 4u;
@@ -140,6 +138,14 @@ __global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
         const uint32_t v = lh[i];
         if (v) atomicAdd(&gh[i], v);
     }
+}
+template <bool SHARED8, bool RAW>
+__global__ __launch_bounds__(kBlockThreads) void k_grad_hist(GradArgs a) {
+    __shared__ uint32_t lh[MUSICA_GRAD_BINS + 64];  // + one scratch word per lane for the branch-free adds
+    __shared__ int s_thr;
+    const int img = blockIdx.z;
+    if (a.only_if && a.only_if[img] == 0u) return;   // block-uniform: nothing to redo for this image
+    grad_hist_body<SHARED8, RAW>(a, img, lh, s_thr);
 }
 
 // histogram from a stored relevant image (kernel-level parity tests, one thread per 16x16 area like the reference)
@@ -271,19 +277,12 @@ __device__ __forceinline__ void block_max_max(uint32_t& a, uint32_t& b, uint32_t
 // gradation_curve_generate.comp:50-193. All integer arithmetic is uint32 and wraps, like GLSL's uint.
 // hist_b / gzero (may be NULL): images whose gzero word is set take their histogram from hist_b — the literal
 // k_grad_hist pass that ran behind the fused expand kernel — and copy it into hist so that every getter sees it.
-__global__ __launch_bounds__(1024) void k_grad_curve(uint32_t* __restrict__ hist, musica_hist_max_point* __restrict__ gmax,
-                                                     DevCurve* __restrict__ curves, const uint32_t* __restrict__ hist_b,
-                                                     const uint32_t* __restrict__ gzero) {
+// `raw`: bin threadIdx.x of the image's histogram (1024 threads)
+__device__ __forceinline__ void grad_curve_body(uint32_t raw, int img, musica_hist_max_point* __restrict__ gmax, DevCurve* __restrict__ curves) {
     __shared__ uint32_t cnt[MUSICA_GRAD_BINS];
     __shared__ uint32_t s32[16], s32b[16];
     __shared__ unsigned long long s64[16];
-    const int img = blockIdx.x;
     const uint32_t i = threadIdx.x;
-    uint32_t raw = hist[(size_t)img * MUSICA_GRAD_BINS + i];
-    if (gzero && gzero[img] != 0u) {
-        raw = hist_b[(size_t)img * MUSICA_GRAD_BINS + i];
-        hist[(size_t)img * MUSICA_GRAD_BINS + i] = raw;
-    }
     const uint32_t count = raw / 100u;                                           // :68
     cnt[i] = count;
     // K12 on the raw histogram (src/vk_processing.cpp:2499, first maximum wins) and the two window sums, one pass
@@ -345,6 +344,53 @@ __global__ __launch_bounds__(1024) void k_grad_curve(uint32_t* __restrict__ hist
     }
     __syncthreads();
     curve_store_parallel(curves + img, cx, cy, &s_mono, 22, t0, ta, t1);                       // :181
+}
+__global__ __launch_bounds__(1024) void k_grad_curve(uint32_t* __restrict__ hist, musica_hist_max_point* __restrict__ gmax,
+                                                     DevCurve* __restrict__ curves, const uint32_t* __restrict__ hist_b,
+                                                     const uint32_t* __restrict__ gzero) {
+    const int img = blockIdx.x;
+    const uint32_t i = threadIdx.x;
+    uint32_t raw = hist[(size_t)img * MUSICA_GRAD_BINS + i];
+    if (gzero && gzero[img] != 0u) {
+        raw = hist_b[(size_t)img * MUSICA_GRAD_BINS + i];
+        hist[(size_t)img * MUSICA_GRAD_BINS + i] = raw;
+    }
+    grad_curve_body(raw, img, gmax, curves);
+}
+
+// The recount and the tone curve in ONE launch, behind a level-0 expand launch that binned every texel (GH): for an image whose gzero
+// word is clear — no reconstructed texel is exactly 0, the usual case — workgroup (0, 0) builds the curve from that histogram and the
+// others return at once (the recount used to be a launch of its own that returned at once: 5 us of every step). For an image that
+// holds a zero every workgroup recounts its share literally (grad_hist_body, 16 wavefronts side by side) into a.hist (= hist_b), draws
+// a ticket once its atomics have landed, and the workgroup that draws the last one reads hist_b back (agent-scope loads: the adds
+// were performed memory-side, across the XCDs), copies it into `hist` for the getters and builds the curve. `ticket`: one word per
+// image, kGradTicketStride apart, zero before and after.
+template <bool SHARED8, bool RAW>
+__global__ __launch_bounds__(1024) void k_grad_recount_curve(GradArgs a, uint32_t* __restrict__ hist, musica_hist_max_point* __restrict__ gmax,
+                                                             DevCurve* __restrict__ curves, uint32_t* __restrict__ ticket) {
+    __shared__ uint32_t lh[MUSICA_GRAD_BINS + 64];
+    __shared__ int s_thr, s_last;
+    const int img = blockIdx.z;
+    uint32_t raw;
+    if (a.only_if[img] == 0u) {   // block-uniform
+        if (blockIdx.x != 0 || blockIdx.y != 0) return;
+        raw = hist[(size_t)img * MUSICA_GRAD_BINS + threadIdx.x];
+    } else {
+        grad_hist_body<SHARED8, RAW>(a, img, lh, s_thr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's adds have been performed
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t* tk = ticket + (size_t)img * kGradTicketStride;
+            const uint32_t t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = t + 1u == gridDim.x * gridDim.y ? 1 : 0;
+            if (s_last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_last) return;   // block-uniform
+        raw = __hip_atomic_load(a.hist + (size_t)img * MUSICA_GRAD_BINS + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hist[(size_t)img * MUSICA_GRAD_BINS + threadIdx.x] = raw;
+    }
+    grad_curve_body(raw, img, gmax, curves);
 }
 
 // ---- K21 (getY of the tone curve: grad_parts.h) --------------------------------------------
@@ -501,6 +547,21 @@ void launch_relevant(hipStream_t st, const float* normalized, const float* cnr, 
     else
         hipLaunchKernelGGL(k_relevant, dim3((l0.S + 31) / 32, (l0.S + 7) / 8, batch), dim3(32, 8), 0, st, normalized, cnr, out, l0.S, l0.pitch,
                            l0.plane, l3.S, l3.pitch, l3.plane, cnrScale);
+}
+
+void launch_grad_recount_curve(hipStream_t st, const GradArgs& a, uint32_t* hist, musica_hist_max_point* gmax, DevCurve* curves, uint32_t* ticket, int batch) {
+    const int col_blocks = (a.N + 256 * 16 - 1) / (256 * 16);   // 16 wavefronts side by side
+    const int groups = (a.N + kHistArea - 1) / kHistArea;
+    const int wave_rows = (groups + a.groups_per_wave - 1) / a.groups_per_wave;
+    const dim3 grid(col_blocks, wave_rows, batch);
+    const bool raw = a.raw != nullptr && (a.N & 3) == 0;
+    if ((a.cnrScale & 7) == 0) {
+        if (raw) hipLaunchKernelGGL((k_grad_recount_curve<true, true>), grid, dim3(1024), 0, st, a, hist, gmax, curves, ticket);
+        else hipLaunchKernelGGL((k_grad_recount_curve<true, false>), grid, dim3(1024), 0, st, a, hist, gmax, curves, ticket);
+    } else {
+        if (raw) hipLaunchKernelGGL((k_grad_recount_curve<false, true>), grid, dim3(1024), 0, st, a, hist, gmax, curves, ticket);
+        else hipLaunchKernelGGL((k_grad_recount_curve<false, false>), grid, dim3(1024), 0, st, a, hist, gmax, curves, ticket);
+    }
 }
 
 void launch_grad_curve(hipStream_t st, uint32_t* hist, musica_hist_max_point* gmax, DevCurve* curves, int batch, const uint32_t* hist_b, const uint32_t* gzero) {

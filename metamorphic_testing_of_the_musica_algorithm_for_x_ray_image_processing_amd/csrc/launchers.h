@@ -113,6 +113,9 @@ void launch_grad_hist(hipStream_t st, const GradArgs& a, int batch);
 void launch_grad_hist_ref(hipStream_t st, const float* img, const float* relevant, const LevelDesc& l0, uint32_t* hist, int batch);
 void launch_relevant(hipStream_t st, const float* normalized, const float* cnr, float* out, const LevelDesc& l0, const LevelDesc& l3,
                      int cnrScale, int batch, const uint16_t* raw = nullptr, const int* thr090 = nullptr);
+// recount (images whose a.only_if word is set, into a.hist) + tone curve in one launch; ticket: [batch][kGradTicketStride] words, zero
+constexpr int kGradTicketStride = 32;
+void launch_grad_recount_curve(hipStream_t st, const GradArgs& a, uint32_t* hist, musica_hist_max_point* gmax, DevCurve* curves, uint32_t* ticket, int batch);
 void launch_grad_curve(hipStream_t st, uint32_t* hist, musica_hist_max_point* gmax, DevCurve* curves, int batch, const uint32_t* hist_b = nullptr, const uint32_t* gzero = nullptr);
 void launch_grad_apply(hipStream_t st, const float* in, float* out, const LevelDesc& l0, const DevCurve* curves, int batch);
 // crop + quantise of saveOutImage for ONE image plane: out = (S - 2 margin)^2 bytes, dense

@@ -73,6 +73,8 @@ struct musica_ctx {
     hipStream_t side1;       // dag == 1: sdev 2 beside the coarse chain
     hipEvent_t ev_s1, ev_s2;
     bool fuse_u16;           // level-0 kernels read the raw uint16 pixels; the normalized image is produced on demand only
+    bool grad_one_launch;    // recount + tone curve in one launch behind the fused expand launch (MUSICA_GRAD_ONE_LAUNCH=0: two)
+    uint32_t* d_gr_ticket;   // its tickets: [B][kGradTicketStride]
     bool tiny_tail;          // levels of side <= kTailSide in one launch (MUSICA_TINY_TAIL=0: one launch per level and stage)
     bool clahe_one_apply;    // ... and whose two apply passes are one launch (MUSICA_CLAHE_ONE_APPLY=0: k_grad_apply and k_clahe_apply4)
     bool clahe_in_expand;    // ... and whose histogram the level-0 expand launch counts (MUSICA_CLAHE_IN_EXPAND=0: k_clahe_hist)
@@ -265,6 +267,7 @@ static musica_ctx* make_view(const musica_ctx* c, int i0, int nb) {
     v->d_minmax += o * kMinMaxStride;
     v->d_mm_slots += o * kMinMaxSlots;
     v->d_mm_ticket += o * kMinMaxStride;
+    v->d_gr_ticket += o * kGradTicketStride;
     v->d_norm += o * c->lv[0].plane;
     for (int i = 0; i < c->L; i++) {
         v->d_down[i] += o * c->lv[i + 1].plane;
@@ -487,12 +490,14 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->clahe_in_expand = env_int("MUSICA_CLAHE_IN_EXPAND", 1) != 0;
     c->clahe_one_apply = env_int("MUSICA_CLAHE_ONE_APPLY", 1) != 0;
     c->tiny_tail = env_int("MUSICA_TINY_TAIL", 1) != 0;
+    c->grad_one_launch = env_int("MUSICA_GRAD_ONE_LAUNCH", 1) != 0;
     c->fuse_gh = env_int("MUSICA_FUSE_GH", 1) != 0 && c->fuse_u16 && (!(params->flags & MUSICA_FLAG_CLAHE) || c->clahe_raw) &&
                  cnr_scale(c->lv[0].S, c->lv[MUSICA_CNR_LEVEL].S) == 8;
     ok = ok && dalloc(c, &c->d_input, B * N * N);
     ok = ok && dalloc(c, &c->d_minmax, B * kMinMaxStride);
     ok = ok && dalloc(c, &c->d_mm_slots, B * kMinMaxSlots);
     ok = ok && dalloc(c, &c->d_mm_ticket, B * kMinMaxStride);   // one 128-byte line per image
+    ok = ok && dalloc(c, &c->d_gr_ticket, B * kGradTicketStride);
     ok = ok && dalloc(c, &c->d_norm, B * c->lv[0].plane);
     for (int i = 0; i < c->L && ok; i++) {
         ok = ok && dalloc(c, &c->d_down[i], B * c->lv[i + 1].plane);
@@ -849,20 +854,20 @@ static void enqueue_gradation(musica_ctx* c, bool fused, bool beside = false) {
         }
         if (beside) hipEventRecord(c->ev_join, c->side);
     }
-    {
-        Span sp(c, MUSICA_KERNEL_GRAD_HIST);
-        GradArgs g;
-        g.img = c->d_recon[0]; g.normalized = c->d_norm; g.cnr = c->d_cnr; g.hist = fused ? c->d_grad_hist_b : c->d_grad_hist;
-        g.only_if = fused ? c->d_gzero : nullptr;
-        g.N = l0.S; g.pitch = l0.pitch; g.plane = l0.plane;
-        g.cnrS = l3.S; g.cnrPitch = l3.pitch; g.cnrPlane = l3.plane; g.cnrScale = scale;
-        g.groups_per_wave = c->grad_groups;
-        g.raw = c->fuse_u16 ? c->cur_input : nullptr;
-        g.minmax = c->d_minmax;
-        g.min_chain_exact = c->min_chain_exact;
-        launch_grad_hist(c->stream, g, c->B);
-    }
-    {
+    GradArgs g;
+    g.img = c->d_recon[0]; g.normalized = c->d_norm; g.cnr = c->d_cnr; g.hist = fused ? c->d_grad_hist_b : c->d_grad_hist;
+    g.only_if = fused ? c->d_gzero : nullptr;
+    g.N = l0.S; g.pitch = l0.pitch; g.plane = l0.plane;
+    g.cnrS = l3.S; g.cnrPitch = l3.pitch; g.cnrPlane = l3.plane; g.cnrScale = scale;
+    g.groups_per_wave = c->grad_groups;
+    g.raw = c->fuse_u16 ? c->cur_input : nullptr;
+    g.minmax = c->d_minmax;
+    g.min_chain_exact = c->min_chain_exact;
+    if (fused && c->grad_one_launch) {   // the recount of images that hold an exact zero and the tone curve in one launch
+        Span sp(c, MUSICA_KERNEL_GRAD_CURVE);
+        launch_grad_recount_curve(c->stream, g, c->d_grad_hist, c->d_grad_max, c->d_gcurve, c->d_gr_ticket, c->B);
+    } else {
+        { Span sp(c, MUSICA_KERNEL_GRAD_HIST); launch_grad_hist(c->stream, g, c->B); }
         Span sp(c, MUSICA_KERNEL_GRAD_CURVE);
         launch_grad_curve(c->stream, c->d_grad_hist, c->d_grad_max, c->d_gcurve, c->B, fused ? c->d_grad_hist_b : nullptr, fused ? c->d_gzero : nullptr);
     }

@@ -211,7 +211,7 @@ def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
             p.cleanup()
 
 
-@pytest.mark.parametrize("env", [{"MUSICA_BAND_TRIP": "1"}, {"MUSICA_EXPAND_TRIP": "2"}, {"MUSICA_U16": "0"}, {"MUSICA_FUSE_GH": "0"}, {"MUSICA_FUSE_RB": "0"}, {"MUSICA_FUSE_RB": "1"}, {"MUSICA_LE090": "0"}, {"MUSICA_XCD_SWIZZLE": "0"},
+@pytest.mark.parametrize("env", [{"MUSICA_BAND_TRIP": "1"}, {"MUSICA_EXPAND_TRIP": "2"}, {"MUSICA_U16": "0"}, {"MUSICA_FUSE_GH": "0"}, {"MUSICA_FUSE_RB": "0"}, {"MUSICA_FUSE_RB": "1"}, {"MUSICA_LE090": "0"}, {"MUSICA_XCD_SWIZZLE": "0"}, {"MUSICA_GRAD_ONE_LAUNCH": "0"}, {"MUSICA_TINY_TAIL": "0"},
                                  {"MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "0"}, {"MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "1"},
                                  {"MUSICA_FUSE_RB": "2", "MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "4"}, {"MUSICA_FUSE_RB": "2", "MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "64"},
                                  {"MUSICA_FUSE_GH": "1", "MUSICA_EXPAND_TRIP": "2"},
@@ -232,14 +232,17 @@ def test_kernel_variants_and_launch_geometries_give_the_same_bits(ob, env, monke
     p.cleanup()
 
 
-@pytest.mark.parametrize("dag", ["0", "1"])
-def test_exact_zeros_in_the_reconstruction_take_the_literal_histogram(ob, dag, monkeypatch):
+@pytest.mark.parametrize("dag,one_launch", [("0", "1"), ("1", "1"), ("2", "1"), ("0", "0")])
+def test_exact_zeros_in_the_reconstruction_take_the_literal_histogram(ob, dag, one_launch, monkeypatch):
     """A collimated image (test/metamorphic_test/script.py's collimator alteration blacks out a frame): raw zeros give
     normalized 0, band 0 and — far enough inside — a reconstruction that is exactly 0, where the reference's histogram
     thread `return`s (gradation_histogram.comp:24) and the noise histogram `break`s (noise_hist.comp:29). The level-0
     expand kernel that bins on the fly must hand such an image to the literal kernel; an image of the same batch
-    without zeros keeps the fused count. Frame edges are not multiples of 16, so areas with texels on both sides exist."""
+    without zeros keeps the fused count. Frame edges are not multiples of 16, so areas with texels on both sides exist.
+    The recount and the tone curve are one launch (k_grad_recount_curve: 64 workgroups recount, the one that draws the last ticket
+    builds the curve; three executes in a row: the tickets re-arm); MUSICA_GRAD_ONE_LAUNCH=0 is the two-launch form."""
     monkeypatch.setenv("MUSICA_DAG", dag)
+    monkeypatch.setenv("MUSICA_GRAD_ONE_LAUNCH", one_launch)
     n, levels = 1024, 4
     a = phantom(n, 61)
     a[:203, :] = 0
