@@ -1237,7 +1237,10 @@ int musica_execute_stream(musica_ctx* c, const uint16_t* const* pixels, uint32_t
     for (uint32_t j = 0; j < count && ok; j++) {
         const int k = (int)(j & 1u);
         if (!pixels[j]) { ok = fail("musica_execute_stream: pixels[%u] is NULL", j); break; }
-        if (j >= 2) hipStreamWaitEvent(c->copy_stream, c->ev_consumed[k], 0);   // batch j - 2 has been computed: its buffer is free
+        // batch j - 2 has been computed: its buffer is free. Waited for on the HOST: a copy-engine queue that waits for a compute
+        // queue's event stalls for ~1 ms at a time on this part (one 2048^2 image per batch: 1.3 ms per batch with the wait on the copy
+        // stream against 0.2 here; devtools/stream_probe.py), and the host has nothing else to do before it may enqueue this copy
+        if (j >= 2 && hipEventSynchronize(c->ev_consumed[k]) != hipSuccess) { ok = fail("musica_execute_stream: waiting for batch %u failed", j - 2); break; }
         if (hipMemcpyAsync(bufs[k], pixels[j], bytes, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) { ok = fail("musica_execute_stream: H2D copy failed"); break; }
         hipEventRecord(c->ev_copied[k], c->copy_stream);
         hipStreamWaitEvent(c->stream, c->ev_copied[k], 0);
