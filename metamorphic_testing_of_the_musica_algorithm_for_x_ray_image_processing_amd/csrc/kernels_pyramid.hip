@@ -516,33 +516,38 @@ __global__ __launch_bounds__(kBlockThreads) void k_band_fast(const float* __rest
 // (four raw halo pixels per row instead of two / one). Every value is produced by the expressions of reduce_row() and
 // lowpass_pair(), so both outputs are bit-identical to the two-kernel path (tested against the oracle and against it).
 // ======================================================================================
+// The strip's halo columns — c0-4 .. c0-1 left of it (lane 0 needs them) and c0+512 .. c0+514 right of it (lane 63) — are spread
+// over the quad of lanes they belong to, ONE column per lane: lane q of the first quad carries column c0-4+q, lane 60+q of the last
+// quad column c0+512+q (round 4; until then every lane carried four halo pixels through normalisation and the vertical chain, a
+// third of both, for two lanes' benefit). The vertical chain runs on that one value; four quad-broadcast DPP moves then hand every
+// lane of a quad all four sums, so lane 0 / 63 evaluate the same expressions on the same values as before.
 struct FRow {
     float v[8];   // normalized pixels c .. c+7
-    float h[4];   // c-4 .. c-1 on lane 0, c+8 .. c+11 on lane 63 (strips with a neighbour on that side; 0 elsewhere)
+    float h;      // lanes 0..3: column c0-4+lane (strips with a left neighbour); lanes 60..63: column c0+512+(lane-60) (strips with a right neighbour); 0 elsewhere
 };
 struct RawF {
     float4 m;     // 8 raw uint16 (bit pattern)
-    float2 h;     // 4 raw halo pixels
+    uint32_t h;   // the lane's raw halo pixel
 };
+__device__ __forceinline__ float quad_bcast0(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x00, 0xF, 0xF, false)); }
+__device__ __forceinline__ float quad_bcast1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x55, 0xF, 0xF, false)); }
+__device__ __forceinline__ float quad_bcast2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xAA, 0xF, 0xF, false)); }
+__device__ __forceinline__ float quad_bcast3(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xFF, 0xF, 0xF, false)); }
 __device__ __forceinline__ void load_raw_f(RawF& r, const Buf& b, uint32_t row_off, uint32_t off, uint32_t off_h) {
     r.m = bload4(b, off + row_off);
-    r.h = bload2(b, off_h + row_off);
+    r.h = bload_u16(b, off_h + row_off);
 }
 __device__ __forceinline__ void convert_f(FRow& r, const RawF& w, const NormK& nk) {
     norm8(r.v, w.m, nk);
-    const uint32_t a = __float_as_uint(w.h.x), b = __float_as_uint(w.h.y);
-    r.h[0] = norm_px(a & 0xFFFFu, nk);
-    r.h[1] = norm_px(a >> 16, nk);
-    r.h[2] = norm_px(b & 0xFFFFu, nk);
-    r.h[3] = norm_px(b >> 16, nk);
+    r.h = norm_px(w.h, nk);
 }
 // One coarse row (the lane's 4 columns + the halo column of an edge lane) from its five fine rows: reduce_row()'s arithmetic.
 __device__ __forceinline__ void coarse_row(CRow& cr, const FRow& r0, const FRow& r1, const FRow& r2, const FRow& r3, const FRow& r4, const LaneCfg& g) {
     float v[8], vh[4];
 #pragma unroll
     for (int j = 0; j < 8; j++) v[j] = chain5(r0.v[j], r1.v[j], r2.v[j], r3.v[j], r4.v[j]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) vh[j] = chain5(r0.h[j], r1.h[j], r2.h[j], r3.h[j], r4.h[j]);
+    const float vq = chain5(r0.h, r1.h, r2.h, r3.h, r4.h);
+    vh[0] = quad_bcast0(vq); vh[1] = quad_bcast1(vq); vh[2] = quad_bcast2(vq); vh[3] = quad_bcast3(vq);   // lane 0: columns c-4 .. c-1; lane 63: c+8 .. c+11
     float vl6 = from_left_lane(v[6]);
     float vl7 = from_left_lane(v[7]);
     float vr0 = from_right_lane(v[0]);
@@ -589,8 +594,7 @@ __device__ __forceinline__ uint32_t le090_bits(const FRow& fe, const FRow& fo) {
 
 __device__ __forceinline__ void load_f(FRow& r, const Buf& b, uint32_t row_off, uint32_t off, uint32_t off_h) {
     load8(r.v, b, off + row_off);
-    const float4 h = bload4(b, off_h + row_off);
-    r.h[0] = h.x; r.h[1] = h.y; r.h[2] = h.z; r.h[3] = h.w;
+    r.h = bload1(b, off_h + row_off);
 }
 
 // rows_per_wave counts coarse rows. grid: x = strips, y = ceil(segments / 4), z = batch.
@@ -603,6 +607,8 @@ __global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __
                                                                int rows_per_wave, const uint32_t* __restrict__ minmax, int min_chain_exact,
                                                                uint16_t* __restrict__ le090, int swz) {
     const int lane = threadIdx.x & 63;
+    const int abl = swz >> 8;   // DEV ablation bits
+    swz &= 255;
     const Tile tile = xcd_tile(swz);
     const int seg = __builtin_amdgcn_readfirstlane((int)(tile.segblock * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
     const int k0 = seg * rows_per_wave;
@@ -628,7 +634,10 @@ __global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __
     // own pixels and four halo pixels: c-4 .. c-1 (lane 0 of a strip that is not the first) or c+8 .. c+11 (lane 63 with more image to its right)
     const uint32_t px_bytes = U16 ? 2u : 4u;
     const uint32_t foff = g.off == kOob ? kOob : (uint32_t)g.c * px_bytes;
-    const uint32_t foff_h = g.off_l != kOob ? (uint32_t)(g.c - 4) * px_bytes : (g.off_r != kOob ? (uint32_t)(g.c + 8) * px_bytes : kOob);
+    // the lane's halo column: c0-4+lane on lanes 0..3 of a strip that is not the first, c0+512+(lane-60) on lanes 60..63 of a strip with more image to its right
+    const int c0s = tile.strip * kStripCols;
+    const uint32_t foff_h = (lane < 4 && c0s > 0 && c0s < S) ? (uint32_t)(c0s - 4 + lane) * px_bytes
+                          : (lane >= 60 && c0s + kStripCols < S) ? (uint32_t)(c0s + kStripCols + lane - 60) * px_bytes : kOob;
     const int hi = S - 1;
     const uint32_t frb = U16 ? (uint32_t)S * 2u : (uint32_t)pitch * 4u, rb = (uint32_t)pitch * 4u, crb = (uint32_t)cpitch * 4u;
     const int ks = max(k0 - 1, 0), ke = min(k1, Sc - 1);   // coarse rows this wavefront computes (the first / last only feed its band rows)
@@ -656,19 +665,19 @@ __global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __
             convert_f(w3, ra, nk);   // the pair requested one trip ago
             convert_f(w4, rc, nk);
             const int kn = min(k + 1, ke);
-            load_raw_f(ra, ib, (uint32_t)mirror_idx(2 * kn + 1, hi) * frb, foff, foff_h);
-            load_raw_f(rc, ib, (uint32_t)mirror_idx(2 * kn + 2, hi) * frb, foff, foff_h);
+            load_raw_f(ra, ib, (uint32_t)((abl & 4) ? 1 : mirror_idx(2 * kn + 1, hi)) * frb, foff, foff_h);
+            load_raw_f(rc, ib, (uint32_t)((abl & 4) ? 2 : mirror_idx(2 * kn + 2, hi)) * frb, foff, foff_h);
         } else {
             load_f(w3, ib, (uint32_t)mirror_idx(2 * k + 1, hi) * frb, foff, foff_h);
             load_f(w4, ib, (uint32_t)mirror_idx(2 * k + 2, hi) * frb, foff, foff_h);
         }
         coarse_row(c0, w0, w1, w2, w3, w4, g);
-        if (k >= k0 && k < k1)  // wave-uniform
+        if (k >= k0 && k < k1 && !(abl & 2))  // wave-uniform
             bstore4_nt(db, g.coff + (uint32_t)k * crb, make_float4(c0.v[0], c0.v[1], c0.v[2], c0.v[3]));
         // coarse row k completes the neighbourhood of row k-1: band rows 2(k-1), 2(k-1)+1 are the two oldest rows of the window.
         // km1(0) = coarse_of_fine(-2) = 1 (reflect-101 on the fine grid, img_smooth_upsampled.comp:10-16): row k itself.
         const int kp = k - 1;
-        if (kp >= k0 && kp < k1) {  // wave-uniform
+        if (kp >= k0 && kp < k1 && !(abl & 1)) {  // wave-uniform
             if (want_mask) bstore_u16(mb, moff + (uint32_t)kp * mrb, le090_bits(w0, w1));
             band_pair(kp == 0 ? c0 : cm2, cm1, c0, w0, w1, g, bb, (uint32_t)(2 * kp) * rb, (uint32_t)(2 * kp + 1) * rb);
         }
@@ -1221,8 +1230,9 @@ void launch_reduce_u16(hipStream_t st, const uint16_t* px, const LevelDesc& li, 
 }
 void launch_reduce_band_u16(hipStream_t st, const uint16_t* px, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                             int rows_per_wave, const uint32_t* minmax, int min_chain_exact, uint16_t* le090) {
+    static const int abl = getenv("MUSICA_RB_ABL") ? atoi(getenv("MUSICA_RB_ABL")) : 0;   // DEV
     hipLaunchKernelGGL(k_reduce_band<true>, stream_grid(lf.S, lc.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, (const void*)px, down, band, lf.S,
-                       lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact, le090, xcd_swizzle_on());
+                       lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact, le090, xcd_swizzle_on() | (abl << 8));
 }
 // levels >= 1 (f32 fine image); the side must be a multiple of 8 and at least 16 (the caller checks)
 void launch_reduce_band(hipStream_t st, const float* fine, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave) {
