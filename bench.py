@@ -373,9 +373,9 @@ def main():
     if rank == 0:
         mpix = world * batch * n * n * args.steps / 1e6
         ms_per_step = elapsed / args.steps * 1e3
-        fused = (n % 8 == 0) and os.environ.get("MUSICA_U16", "1") != "0"
-        rb_mode = int(os.environ.get("MUSICA_FUSE_RB", "2")) if proc.fuses_reduce_band() else 0
-        le090 = bool(proc.fuses_gradhist() and rb_mode >= 1 and os.environ.get("MUSICA_LE090", "1") != "0")
+        fused = n % 8 == 0
+        rb_mode = 2 if proc.fuses_reduce_band() else 0
+        le090 = bool(proc.fuses_gradhist() and rb_mode >= 1)
         ab = algorithmic_bytes(n, levels, batch, fused, fused_gradhist=proc.fuses_gradhist(), fused_rb=rb_mode, le090=le090)
         kernels = {}
         total_kernel_us = 0.0

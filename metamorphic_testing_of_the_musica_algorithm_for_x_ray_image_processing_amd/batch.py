@@ -29,10 +29,11 @@ def row_to_stats(row):
     return Stats.from_buffer_copy(np.ascontiguousarray(row, dtype=np.int32).tobytes())
 
 
-def gather_rows(local_rows, world, dist=None, device=None):
+def gather_rows(local_rows, world, dist=None, device=None, force_collective=False):
     """All-gather equal-sized int32 row blocks; returns int32[world * rows, STATS_WORDS] on every rank.
 
     `local_rows` is a numpy int32 array (CPU / gloo) or a torch tensor already on `device` (GPU / RCCL).
+    `force_collective`: run the collective even in a job of one rank (the one-GPU test of the RCCL path).
     """
     import torch
     if isinstance(local_rows, np.ndarray):
@@ -41,7 +42,7 @@ def gather_rows(local_rows, world, dist=None, device=None):
             t = t.to(device)
     else:
         t = local_rows
-    if world == 1 or dist is None:
+    if dist is None or (world == 1 and not force_collective):
         return t                 # one rank: the rows are the job's rows (no copy, no kernel)
     if t.is_cuda and dist.get_backend() == "gloo":
         # one-GPU rehearsal of the multi-rank flow (bench.py --backend gloo): the rows travel through host memory

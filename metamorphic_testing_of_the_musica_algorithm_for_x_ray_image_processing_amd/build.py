@@ -3,7 +3,9 @@
     python -m metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.build
 
 -ffp-contract=off keeps every f32 multiply and add separately rounded (the parity contract with
-oracle/musica_oracle.c); IEEE division and sqrt are hipcc's default for HIP.
+oracle/musica_oracle.c); IEEE division and sqrt are hipcc's default for HIP. -fno-slp-vectorize: on gfx950 a packed
+f32 multiply or add costs what two plain ones cost, and the pairs the SLP vectoriser builds cost v_mov on top (the
+kernels write the one packed form that pays, v_pk_fma_f32, themselves; profiles/r04_rb0_experiments.txt).
 """
 import os
 import subprocess
@@ -16,7 +18,7 @@ CLI = os.path.join(HERE, "musica-standalone")
 HIP_SOURCES = ["kernels_pyramid.hip", "kernels_analysis.hip", "kernels_gradation.hip", "kernels_clahe.hip", "kernels_bench.hip", "musica_ctx.hip"]
 CPP_SOURCES = ["musica_io.cpp"]
 HEADERS = ["musica_device.h", "kernels_common.h", "exact_math.h", "sdev_parts.h", "grad_parts.h", "launchers.h", os.path.join("..", "..", "include", "musica.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
 def _hipcc():

@@ -8,11 +8,15 @@ namespace musica {
 
 // ---- cross-lane moves on the 64-wide wavefront (DPP wave shifts, no LDS) ----
 // wave_shr:1 — lane i receives lane i-1 (lane 0 receives 0); wave_shl:1 — lane i receives lane i+1.
+// (bound_ctrl = 1: the lane without a source receives 0 from the instruction itself — with bound_ctrl = 0 and an `old` operand of 0
+// the compiler had to zero the destination with a v_mov in front of every DPP move.)
 __device__ __forceinline__ float from_left_lane(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+    const int s = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(s, s, 0x138, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float from_right_lane(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+    const int s = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(s, s, 0x130, 0xF, 0xF, true));
 }
 
 // ---- branch-free memory access through buffer descriptors ----

@@ -79,6 +79,8 @@ __device__ __forceinline__ void store8(const Buf& b, uint32_t off, const float d
     bstore4(b, off, make_float4(d[0], d[1], d[2], d[3]));
     bstore4(b, off + 16u, make_float4(d[4], d[5], d[6], d[7]));
 }
+// a + b for two byte offsets either of which may be kOob ("nothing to access"): the sum of two markers wraps to 0, so the marker bit is ORed back in
+__device__ __forceinline__ uint32_t oob_add(uint32_t a, uint32_t b) { return (a + b) | ((a | b) & kOob); }
 __device__ __forceinline__ void store8_nt(const Buf& b, uint32_t off, const float d[8]) {
     bstore4_nt(b, off, make_float4(d[0], d[1], d[2], d[3]));
     bstore4_nt(b, off + 16u, make_float4(d[4], d[5], d[6], d[7]));
@@ -225,91 +227,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_dma(const float* __res
 // starts. Here the level-0 kernels read the uint16 pixels (2 B/px) and apply img_sqrt.comp:15 +
 // img_normalize.comp:24 to every pixel they load — the same three IEEE operations k_normalize executes,
 // so the values are bit-identical — and the normalized image is only produced on demand.
-struct RawRow {
-    float4 m;      // 8 uint16 pixels c .. c+7 (bit pattern)
-    float hl, hr;  // pixel pairs (c-2, c-1) and (c+8, c+9) (bit pattern)
-};
-struct U16Cfg {
-    uint32_t off, off_l, off_r;  // byte offsets inside a dense uint16 row; kOob where nothing is to be read
-};
-__device__ __forceinline__ U16Cfg make_u16cfg(const LaneCfg& g) {
-    U16Cfg u;
-    u.off = g.off == kOob ? kOob : g.off >> 1;
-    u.off_l = g.off_l == kOob ? kOob : g.off_l >> 1;
-    u.off_r = g.off_r == kOob ? kOob : g.off_r >> 1;
-    return u;
-}
-__device__ __forceinline__ void load_raw_row(RawRow& r, const Buf& b, uint32_t row_off, const U16Cfg& u) {
-    r.m = bload4(b, u.off + row_off);
-    r.hl = bload1(b, u.off_l + row_off);
-    r.hr = bload1(b, u.off_r + row_off);
-}
 __device__ __forceinline__ void norm8(float d[8], float4 m, const NormK& nk) {
     const uint32_t w[4] = {__float_as_uint(m.x), __float_as_uint(m.y), __float_as_uint(m.z), __float_as_uint(m.w)};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         d[2 * k] = norm_px(w[k] & 0xFFFFu, nk);
         d[2 * k + 1] = norm_px(w[k] >> 16, nk);
-    }
-}
-__device__ __forceinline__ void convert_row(RowR& r, const RawRow& w, const LaneCfg& g, const NormK& nk) {
-    norm8(r.v, w.m, nk);
-    const uint32_t l = __float_as_uint(w.hl), h = __float_as_uint(w.hr);
-    // halo values only matter on lane 0 / lane 63 of strips that have a neighbour; elsewhere the loads returned 0
-    // (lane 0 uses hl0 / hl1, lane 63 uses hr: one conversion serves both ends, and with hr == hl0 the
-    // vertical chains of reduce_row over hr and hl0 are the same expression)
-    const float ends = norm_px(g.lane63 ? (h & 0xFFFFu) : (l & 0xFFFFu), nk);
-    r.hl0 = ends;
-    r.hl1 = norm_px(l >> 16, nk);
-    r.hr = ends;
-}
-
-// K1 + K4 + K5 + K6 at level 0: the pipelined kernel above with uint16 input.
-// Algorithmic bytes: 2 * S^2 in + 4 * (S/2)^2 out = 3 bytes per input pixel.
-__global__ __launch_bounds__(kBlockThreads) void k_reduce_u16_pf(const uint16_t* __restrict__ px, float* __restrict__ out, int S,
-                                                                 int So, int opitch, size_t out_plane, int rows_per_wave,
-                                                                 const uint32_t* __restrict__ minmax, int min_chain_exact) {
-    const int lane = threadIdx.x & 63;
-    const int seg = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
-    const int yo0 = seg * rows_per_wave;
-    if (yo0 >= So) return;  // wave-uniform
-    const int yo1 = min(yo0 + rows_per_wave, So);
-    const int img = blockIdx.z;
-    float minv, maxv;
-    chain_scalars(minmax, img, min_chain_exact, minv, maxv);
-    const NormK nk = make_norm(minv, maxv);
-    const Buf ib = make_buf(px + (size_t)img * S * S, (size_t)S * S * 2);
-    const Buf ob = make_buf(out + (size_t)img * out_plane, out_plane * 4);
-    const LaneCfg g = make_cfg(blockIdx.x, lane, S);
-    const U16Cfg u = make_u16cfg(g);
-    const int hi = S - 1;
-    const uint32_t rb = (uint32_t)S * 2u, orb = (uint32_t)opitch * 4u;
-    // Odd segments march upwards, even ones downwards: two vertically adjacent wavefronts then touch their 3 shared halo rows
-    // at the same moment, so the second reader hits the XCD's L2. Window slot k holds input row 2*yo + dir*(k-2); chain5
-    // always gets the rows in top-to-bottom order.
-    const int dir = (seg & 1) ? -1 : 1;
-    const int n = yo1 - yo0;
-    const int yfirst = dir > 0 ? yo0 : yo1 - 1;
-    RowR w0, w1, w2, w3, w4;
-    RawRow a, b;
-    load_raw_row(a, ib, (uint32_t)mirror_idx(2 * yfirst - 2 * dir, hi) * rb, u);
-    convert_row(w0, a, g, nk);
-    load_raw_row(a, ib, (uint32_t)mirror_idx(2 * yfirst - dir, hi) * rb, u);
-    convert_row(w1, a, g, nk);
-    load_raw_row(a, ib, (uint32_t)(2 * yfirst) * rb, u);
-    convert_row(w2, a, g, nk);
-    load_raw_row(a, ib, (uint32_t)mirror_idx(2 * yfirst + dir, hi) * rb, u);
-    load_raw_row(b, ib, (uint32_t)mirror_idx(2 * yfirst + 2 * dir, hi) * rb, u);
-    for (int t = 0; t < n; t++) {
-        const int yo = yfirst + dir * t;
-        convert_row(w3, a, g, nk);   // the pair requested one trip ago
-        convert_row(w4, b, g, nk);
-        const int yn = yfirst + dir * min(t + 1, n - 1);
-        load_raw_row(a, ib, (uint32_t)mirror_idx(2 * yn + dir, hi) * rb, u);
-        load_raw_row(b, ib, (uint32_t)mirror_idx(2 * yn + 2 * dir, hi) * rb, u);
-        if (dir > 0) reduce_row(w0, w1, w2, w3, w4, g, ob, (uint32_t)yo * orb);  // wave-uniform
-        else reduce_row(w4, w3, w2, w1, w0, g, ob, (uint32_t)yo * orb);
-        w0 = w2; w1 = w3; w2 = w4;
     }
 }
 
@@ -438,73 +361,6 @@ __device__ __forceinline__ void lowpass_pair(const CRow& a, const CRow& b, const
     hpass8(Vo, l, r, lowO);
 }
 
-// K7 + K8 + K9: band = fine - lowpass(coarse). rows_per_wave counts COARSE rows (2 fine rows each);
-// T coarse rows per loop trip (T + 4T 16-byte loads per lane in flight).
-// U16: the fine image is the raw uint16 input (dense rows of S pixels), normalised on the fly (level 0).
-template <int T, bool U16>
-__global__ __launch_bounds__(kBlockThreads) void k_band_fast(const float* __restrict__ fine, const float* __restrict__ coarse,
-                                                             float* __restrict__ band, int S, int pitch, size_t plane,
-                                                             int Sc, int cpitch, size_t cplane, int rows_per_wave,
-                                                             const uint32_t* __restrict__ minmax, int min_chain_exact) {
-    const int lane = threadIdx.x & 63;
-    const int seg = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
-    const int k0 = seg * rows_per_wave;
-    if (k0 >= Sc) return;
-    const int k1 = min(k0 + rows_per_wave, Sc);
-    NormK nk = make_norm(0.0f, 1.0f);
-    if (U16) {
-        float minv, maxv;
-        chain_scalars(minmax, blockIdx.z, min_chain_exact, minv, maxv);
-        nk = make_norm(minv, maxv);
-    }
-    const Buf fb = U16 ? make_buf(reinterpret_cast<const uint16_t*>(fine) + (size_t)blockIdx.z * S * S, (size_t)S * S * 2)
-                       : make_buf(fine + (size_t)blockIdx.z * plane, plane * 4);
-    const Buf bb = make_buf(band + (size_t)blockIdx.z * plane, plane * 4);
-    const Buf cb = make_buf(coarse + (size_t)blockIdx.z * cplane, cplane * 4);
-    const LaneCfg g = make_cfg(blockIdx.x, lane, S);
-    const uint32_t rb = (uint32_t)pitch * 4u, crb = (uint32_t)cpitch * 4u;
-    const uint32_t urb = (uint32_t)S * 2u, uoff = g.off == kOob ? kOob : g.off >> 1;
-
-    CRow cw[T + 2];  // coarse rows km1(k), k .. k+T-1, kp1(k+T-1)
-    load_crow(cw[0], cb, (uint32_t)coarse_of_fine(2 * k0 - 2, S) * crb, g);
-    load_crow(cw[1], cb, (uint32_t)k0 * crb, g);
-    for (int k = k0; k < k1; k += T) {
-        float fe[T][8], fo[T][8];
-        float4 re[T], ro[T];  // raw uint16 rows (U16)
-#pragma unroll
-        for (int t = 0; t < T; t++) {
-            const int ka = min(k + t, k1 - 1);
-            load_crow(cw[t + 2], cb, (uint32_t)coarse_of_fine(2 * ka + 2, S) * crb, g);
-            if (U16) {
-                re[t] = bload4(fb, uoff + (uint32_t)(2 * ka) * urb);
-                ro[t] = bload4(fb, uoff + (uint32_t)(2 * ka + 1) * urb);
-            } else {
-                load8(fe[t], fb, g.off + (uint32_t)(2 * ka) * rb);
-                load8(fo[t], fb, g.off + (uint32_t)(2 * ka + 1) * rb);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < T; t++) {
-            if (k + t < k1) {  // wave-uniform
-                if (U16) {
-                    norm8(fe[t], re[t], nk);
-                    norm8(fo[t], ro[t], nk);
-                }
-                float lowE[8], lowO[8];
-                lowpass_pair(cw[t], cw[t + 1], cw[t + 2], g, lowE, lowO);
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    fe[t][j] = fe[t][j] - lowE[j];   // img_difference.comp:15
-                    fo[t][j] = fo[t][j] - lowO[j];
-                }
-                store8(bb, g.off + (uint32_t)(2 * (k + t)) * rb, fe[t]);
-                store8(bb, g.off + (uint32_t)(2 * (k + t) + 1) * rb, fo[t]);
-            }
-        }
-        cw[0] = cw[T]; cw[1] = cw[T + 1];
-    }
-}
-
 // ======================================================================================
 // Level 0 in one march: K1 + K4 + K5 + K6 and K7 + K8 + K9 — smooth + downsample AND the band-pass image — from one read
 // of the fine image. Separately, k_reduce_u16_pf and k_band_fast<., true> each read and normalise the whole image
@@ -529,10 +385,10 @@ struct RawF {
     float4 m;     // 8 raw uint16 (bit pattern)
     uint32_t h;   // the lane's raw halo pixel
 };
-__device__ __forceinline__ float quad_bcast0(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x00, 0xF, 0xF, false)); }
-__device__ __forceinline__ float quad_bcast1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x55, 0xF, 0xF, false)); }
-__device__ __forceinline__ float quad_bcast2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xAA, 0xF, 0xF, false)); }
-__device__ __forceinline__ float quad_bcast3(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xFF, 0xF, 0xF, false)); }
+__device__ __forceinline__ float quad_bcast0(float v) { const int s = __builtin_bit_cast(int, v); return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(s, s, 0x00, 0xF, 0xF, true)); }
+__device__ __forceinline__ float quad_bcast1(float v) { const int s = __builtin_bit_cast(int, v); return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(s, s, 0x55, 0xF, 0xF, true)); }
+__device__ __forceinline__ float quad_bcast2(float v) { const int s = __builtin_bit_cast(int, v); return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(s, s, 0xAA, 0xF, 0xF, true)); }
+__device__ __forceinline__ float quad_bcast3(float v) { const int s = __builtin_bit_cast(int, v); return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(s, s, 0xFF, 0xF, 0xF, true)); }
 __device__ __forceinline__ void load_raw_f(RawF& r, const Buf& b, uint32_t row_off, uint32_t off, uint32_t off_h) {
     r.m = bload4(b, off + row_off);
     r.h = bload_u16(b, off_h + row_off);
@@ -607,8 +463,6 @@ __global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __
                                                                int rows_per_wave, const uint32_t* __restrict__ minmax, int min_chain_exact,
                                                                uint16_t* __restrict__ le090, int swz) {
     const int lane = threadIdx.x & 63;
-    const int abl = swz >> 8;   // DEV ablation bits
-    swz &= 255;
     const Tile tile = xcd_tile(swz);
     const int seg = __builtin_amdgcn_readfirstlane((int)(tile.segblock * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
     const int k0 = seg * rows_per_wave;
@@ -665,19 +519,19 @@ __global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __
             convert_f(w3, ra, nk);   // the pair requested one trip ago
             convert_f(w4, rc, nk);
             const int kn = min(k + 1, ke);
-            load_raw_f(ra, ib, (uint32_t)((abl & 4) ? 1 : mirror_idx(2 * kn + 1, hi)) * frb, foff, foff_h);
-            load_raw_f(rc, ib, (uint32_t)((abl & 4) ? 2 : mirror_idx(2 * kn + 2, hi)) * frb, foff, foff_h);
+            load_raw_f(ra, ib, (uint32_t)mirror_idx(2 * kn + 1, hi) * frb, foff, foff_h);
+            load_raw_f(rc, ib, (uint32_t)mirror_idx(2 * kn + 2, hi) * frb, foff, foff_h);
         } else {
             load_f(w3, ib, (uint32_t)mirror_idx(2 * k + 1, hi) * frb, foff, foff_h);
             load_f(w4, ib, (uint32_t)mirror_idx(2 * k + 2, hi) * frb, foff, foff_h);
         }
         coarse_row(c0, w0, w1, w2, w3, w4, g);
-        if (k >= k0 && k < k1 && !(abl & 2))  // wave-uniform
+        if (k >= k0 && k < k1)  // wave-uniform
             bstore4_nt(db, g.coff + (uint32_t)k * crb, make_float4(c0.v[0], c0.v[1], c0.v[2], c0.v[3]));
         // coarse row k completes the neighbourhood of row k-1: band rows 2(k-1), 2(k-1)+1 are the two oldest rows of the window.
         // km1(0) = coarse_of_fine(-2) = 1 (reflect-101 on the fine grid, img_smooth_upsampled.comp:10-16): row k itself.
         const int kp = k - 1;
-        if (kp >= k0 && kp < k1 && !(abl & 1)) {  // wave-uniform
+        if (kp >= k0 && kp < k1) {  // wave-uniform
             if (want_mask) bstore_u16(mb, moff + (uint32_t)kp * mrb, le090_bits(w0, w1));
             band_pair(kp == 0 ? c0 : cm2, cm1, c0, w0, w1, g, bb, (uint32_t)(2 * kp) * rb, (uint32_t)(2 * kp + 1) * rb);
         }
@@ -830,10 +684,12 @@ __device__ __forceinline__ float curve_eval_lut(const CurveLds& t, const LutLds&
 // value ((r*r)*(r*r))*r itself 1.0 or cnr in [6, 256] with `normalized <= 0.9`. A workgroup's 512 columns and its rows touch at
 // most 2 x 2 tiles (the launcher checks: tile side >= 512 and >= the workgroup's rows): lc = 2 copies x 4 tile slots x 256 bins.
 constexpr int kChSlots = 4, kChCopies = 2;
-template <int GAIN, bool NR, int T, bool GH, bool MASK, bool LUTOK, bool CNR48, bool CH = false>
+template <int GAIN, bool NR, bool GH, bool LUTOK, bool CNR48, bool CH = false>
 __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds& tab, const LutLds& lut, uint32_t* lh, int img, uint32_t* lc = nullptr,
                                              uint32_t tx0 = 0u, uint32_t ty0 = 0u) {
     constexpr int kGhCopies = 4, kGhStride = MUSICA_GRAD_BINS + 8;
+    constexpr int T = 1;          // coarse rows per trip (two per trip lost everywhere it was measured and left in round 4)
+    constexpr bool MASK = true;   // `normalized <= 0.9` always comes as k_reduce_band<true>'s bit image (the raw-pixel form left in round 4)
     // slope of noise_reduction.comp:28, the same value for every texel
     const float nr_m = (a.highFactor - a.lowFactor) / (a.highCnr - a.lowCnr);
     const int lane = threadIdx.x & 63;
@@ -984,7 +840,7 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
     return saw_zero;
 }
 
-template <int GAIN, bool NR, int T, bool GH, int W = 1, bool MASK = false, bool CH = false>
+template <int GAIN, bool NR, bool GH, int W = 1, bool CH = false>
 __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) {
     __shared__ CurveLds tab;
     __shared__ __attribute__((aligned(16))) LutLds lut;
@@ -1016,10 +872,10 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
     const bool lut_ok = GAIN != GAIN_CURVE || __builtin_amdgcn_readfirstlane((int)lut.ok) != 0;
     const bool cnr48 = !NR || GH || a.cnrScale == 4 || a.cnrScale == 8;   // kernel argument: uniform
     bool saw_zero;
-    if (lut_ok && cnr48) saw_zero = expand_march<GAIN, NR, T, GH, MASK, true, true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
-    else if (lut_ok) saw_zero = expand_march<GAIN, NR, T, GH, MASK, true, NR && !GH ? false : true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
-    else if (cnr48) saw_zero = expand_march<GAIN, NR, T, GH, MASK, GAIN != GAIN_CURVE, true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
-    else saw_zero = expand_march<GAIN, NR, T, GH, MASK, GAIN != GAIN_CURVE, NR && !GH ? false : true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
+    if (lut_ok && cnr48) saw_zero = expand_march<GAIN, NR, GH, true, true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
+    else if (lut_ok) saw_zero = expand_march<GAIN, NR, GH, true, NR && !GH ? false : true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
+    else if (cnr48) saw_zero = expand_march<GAIN, NR, GH, GAIN != GAIN_CURVE, true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
+    else saw_zero = expand_march<GAIN, NR, GH, GAIN != GAIN_CURVE, NR && !GH ? false : true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
     if (GH) {
         if (saw_zero) atomicOr(&a.gzero[img], 1u);
         __syncthreads();
@@ -1222,45 +1078,20 @@ void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* 
     }
 }
 
-// Level 0 from the raw uint16 pixels (S % 8 == 0 only; the caller checks).
-void launch_reduce_u16(hipStream_t st, const uint16_t* px, const LevelDesc& li, float* out, const LevelDesc& lo, int batch, int rows_per_wave,
-                       const uint32_t* minmax, int min_chain_exact) {
-    hipLaunchKernelGGL(k_reduce_u16_pf, stream_grid(li.S, lo.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, px, out, li.S, lo.S, lo.pitch,
-                       lo.plane, rows_per_wave, minmax, min_chain_exact);
-}
 void launch_reduce_band_u16(hipStream_t st, const uint16_t* px, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
                             int rows_per_wave, const uint32_t* minmax, int min_chain_exact, uint16_t* le090) {
-    static const int abl = getenv("MUSICA_RB_ABL") ? atoi(getenv("MUSICA_RB_ABL")) : 0;   // DEV
     hipLaunchKernelGGL(k_reduce_band<true>, stream_grid(lf.S, lc.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, (const void*)px, down, band, lf.S,
-                       lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact, le090, xcd_swizzle_on() | (abl << 8));
+                       lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact, le090, xcd_swizzle_on());
 }
 // levels >= 1 (f32 fine image); the side must be a multiple of 8 and at least 16 (the caller checks)
 void launch_reduce_band(hipStream_t st, const float* fine, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave) {
     hipLaunchKernelGGL(k_reduce_band<false>, stream_grid(lf.S, lc.S, rows_per_wave, batch), dim3(kBlockThreads), 0, st, (const void*)fine, down, band, lf.S,
                        lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, (const uint32_t*)nullptr, 0, (uint16_t*)nullptr, xcd_swizzle_on());
 }
-void launch_band_u16(hipStream_t st, const uint16_t* px, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch,
-                     int rows_per_wave, int rows_per_trip, const uint32_t* minmax, int min_chain_exact) {
-    const dim3 grid = stream_grid(lf.S, lc.S, rows_per_wave, batch);
-    const float* fine = reinterpret_cast<const float*>(px);
-    if (rows_per_trip >= 2)
-        hipLaunchKernelGGL((k_band_fast<2, true>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
-    else
-        hipLaunchKernelGGL((k_band_fast<1, true>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, minmax, min_chain_exact);
-}
-
-void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc,
-                 int batch, int rows_per_wave, bool force_generic, int rows_per_trip, int ref) {
-    if (fast_ok(lf.S) && !force_generic) {
-        const dim3 grid = stream_grid(lf.S, lc.S, rows_per_wave, batch);
-        if (rows_per_trip >= 2)
-            hipLaunchKernelGGL((k_band_fast<2, false>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, nullptr, 0);
-        else
-            hipLaunchKernelGGL((k_band_fast<1, false>), grid, dim3(kBlockThreads), 0, st, fine, coarse, band, lf.S, lf.pitch, lf.plane, lc.S, lc.pitch, lc.plane, rows_per_wave, nullptr, 0);
-    } else {
-        hipLaunchKernelGGL(k_band_generic, generic_grid(lf.S, batch), kGenericBlock, 0, st, fine, coarse, band, lf.S, lf.pitch,
-                           lf.plane, lc.S, lc.pitch, lc.plane, ref);
-    }
+// band of a level that does not take the fused reduce + band march (sides that are not a multiple of 8, generic / literal-order contexts)
+void launch_band(hipStream_t st, const float* fine, const float* coarse, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int ref) {
+    hipLaunchKernelGGL(k_band_generic, generic_grid(lf.S, batch), kGenericBlock, 0, st, fine, coarse, band, lf.S, lf.pitch,
+                       lf.plane, lc.S, lc.pitch, lc.plane, ref);
 }
 
 void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch, int ref) {
@@ -1269,29 +1100,26 @@ void launch_lowpass(hipStream_t st, const float* coarse, float* low, const Level
 }
 
 template <int GAIN, bool NR>
-static void launch_expand_t(hipStream_t st, const ExpandArgs& a, int batch, bool force_generic, int rows_per_trip) {
+static void launch_expand_t(hipStream_t st, const ExpandArgs& a, int batch, bool force_generic) {
     if (fast_ok(a.S) && !force_generic) {
         const dim3 grid = stream_grid(a.S, a.Sc, a.rows_per_wave, batch);
-        if (GAIN == GAIN_CURVE && NR && a.ghist) {   // level 0 with the gradation histogram on board (the caller checked cnrScale == 8)
-            // W = 4: register allocation capped at 128 (4 wavefronts per SIMD, 16 dwords of scratch) against 143 registers and 3 wavefronts
-            // a.chist: only with le090, a tile side (S / 4) of at least a strip and at least the rows of a workgroup (the caller checks)
-            if (a.le090 && a.chist) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 4, true, true>), grid, dim3(kBlockThreads), 0, st, a);
-            else if (a.le090) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 4, true>), grid, dim3(kBlockThreads), 0, st, a);
-            else if (rows_per_trip >= 2) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 2, true>), grid, dim3(kBlockThreads), 0, st, a);
-            else hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, 1, true, 4>), grid, dim3(kBlockThreads), 0, st, a);
+        if (GAIN == GAIN_CURVE && NR && a.ghist) {   // level 0 with the gradation histogram on board (the caller checked cnrScale == 8 and passes le090)
+            // W = 4: register allocation capped at 128 (4 wavefronts per SIMD) against 143 registers and 3 wavefronts
+            // a.chist: a tile side (S / 4) of at least a strip and at least the rows of a workgroup (the caller checks)
+            if (a.chist) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, true, 4, true>), grid, dim3(kBlockThreads), 0, st, a);
+            else hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, true, 4>), grid, dim3(kBlockThreads), 0, st, a);
         }
-        else if (rows_per_trip >= 2) hipLaunchKernelGGL((k_expand_fast<GAIN, NR, 2, false>), grid, dim3(kBlockThreads), 0, st, a);
-        else hipLaunchKernelGGL((k_expand_fast<GAIN, NR, 1, false, NR ? 4 : 1>), grid, dim3(kBlockThreads), 0, st, a);   // NR: 129 registers wanted, capped at 128 (4 wavefronts per SIMD)
+        else hipLaunchKernelGGL((k_expand_fast<GAIN, NR, false, NR ? 4 : 1>), grid, dim3(kBlockThreads), 0, st, a);   // NR: 129 registers wanted, capped at 128 (4 wavefronts per SIMD)
     } else {
         hipLaunchKernelGGL((k_expand_generic<GAIN, NR>), generic_grid(a.S, batch), kGenericBlock, 0, st, a);
     }
 }
 
-void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic, int rows_per_trip) {
-    if (gain_mode == GAIN_CONST) launch_expand_t<GAIN_CONST, false>(st, a, batch, force_generic, rows_per_trip);
-    else if (gain_mode == GAIN_RANGE) launch_expand_t<GAIN_RANGE, false>(st, a, batch, force_generic, rows_per_trip);
-    else if (nr) launch_expand_t<GAIN_CURVE, true>(st, a, batch, force_generic, rows_per_trip);
-    else launch_expand_t<GAIN_CURVE, false>(st, a, batch, force_generic, rows_per_trip);
+void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic) {
+    if (gain_mode == GAIN_CONST) launch_expand_t<GAIN_CONST, false>(st, a, batch, force_generic);
+    else if (gain_mode == GAIN_RANGE) launch_expand_t<GAIN_RANGE, false>(st, a, batch, force_generic);
+    else if (nr) launch_expand_t<GAIN_CURVE, true>(st, a, batch, force_generic);
+    else launch_expand_t<GAIN_CURVE, false>(st, a, batch, force_generic);
 }
 
 void launch_exp_band(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch) {

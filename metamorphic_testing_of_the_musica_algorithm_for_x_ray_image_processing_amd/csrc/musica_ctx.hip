@@ -70,8 +70,6 @@ struct musica_ctx {
     hipStream_t cur;         // stream the run_*_level helpers launch on (stream or side)
     hipStream_t side;        // coarse-level chain runs here, concurrently with the level-0 kernels on `stream`
     hipEvent_t ev_fork, ev_join;
-    hipStream_t side1;       // dag == 1: sdev 2 beside the coarse chain
-    hipEvent_t ev_s1, ev_s2;
     bool fuse_u16;           // level-0 kernels read the raw uint16 pixels; the normalized image is produced on demand only
     bool grad_one_launch;    // recount + tone curve in one launch behind the fused expand launch (MUSICA_GRAD_ONE_LAUNCH=0: two)
     uint32_t* d_gr_ticket;   // its tickets: [B][kGradTicketStride]
@@ -87,7 +85,7 @@ struct musica_ctx {
     const uint16_t* graph_input[kGraphSlots];    // path alternates between two device input buffers; callers may rotate a few of their own)
     uint64_t graph_used[kGraphSlots];            // launch counter at the slot's last use (least recently used slot is recaptured)
     uint64_t graph_clock;
-    int dag;                 // 0: one in-order stream; 1: three streams (levels 0-1 | coarse chain | sdev 2)
+    int dag;                 // 0: one in-order stream (enqueue_linear); 2: two streams (enqueue_fork: the analysis beside the reduce tail)
     // device state
     uint16_t* d_input;
     uint16_t* d_input2;      // second input buffer of the streaming path (musica_execute_stream), allocated on first use
@@ -116,8 +114,6 @@ struct musica_ctx {
     double* d_stats_partial;   // [B][kStatsMaxBlocks]: partial sums of the cnr image (k_stats_partial -> k_stats)
     uint16_t* d_le090;         // [B][S1][S0 / 8] or null: its bit image, written by the level-0 reduce + band launch for the level-0 expand launch
     bool fuse_gh;              // the level-0 expand launch accumulates the gradation histogram
-    int fuse_rb;               // smooth + downsample and the band-pass image of a level in one launch (k_reduce_band): 0 off, 1 level 0 only,
-                               // 2 every level whose side is a multiple of 8
     int rows_rb[MUSICA_MAX_LEVELS];   // its coarse rows per wavefront
     musica_hist_max_point* d_grad_max;
     DevCurve* d_gcurve;
@@ -133,9 +129,9 @@ struct musica_ctx {
     musica_contrast_params h_cparams[MUSICA_MAX_LEVELS];
     musica_nr_params h_nr[3];
     // rows each wavefront marches per launch, per level (heuristic, then autotuned at create)
-    int rows_reduce[MUSICA_MAX_LEVELS], rows_band[MUSICA_MAX_LEVELS], rows_expand[MUSICA_MAX_LEVELS], rows_sdev[4];
+    int rows_expand[MUSICA_MAX_LEVELS], rows_sdev[4];
     // tunables
-    int reduce_rows, band_rows, expand_rows, sdev_rows, grad_groups, band_trip, expand_trip, min_waves;
+    int expand_rows, sdev_rows, grad_groups, min_waves;
     // profiling
     uint32_t profiling;  // bit i set: bracket kernel family i with HIP events
     std::vector<ProfSpan> spans;
@@ -143,13 +139,6 @@ struct musica_ctx {
     double prof_total_us[MUSICA_KERNEL_COUNT];
     uint64_t prof_count[MUSICA_KERNEL_COUNT];
     std::vector<void*> allocations;
-    // Image groups: the batch is cut into `views` (shallow copies of this context whose device pointers start at
-    // the group's first image and whose B is the group's size, each with its own pair of streams). The groups are
-    // independent pipelines, so their dependent chains of small, latency-bound kernels overlap with each other's
-    // bandwidth-bound level-0 kernels instead of leaving the chip idle. Empty when the batch runs as one group.
-    std::vector<musica_ctx*> views;
-    hipEvent_t ev_gfork, ev_gdone;   // parent: fork point; view: end of the group's pipeline
-    int first_image;                 // view: index of its first image in the parent's batch
 };
 
 static int env_int(const char* name, int dflt) {
@@ -200,6 +189,12 @@ static musica_nr_params host_nr_params(uint32_t i) {
 
 static void autotune(musica_ctx* c);
 static bool rb_level(const musica_ctx* c, int i);
+static void copy_rows(musica_ctx* dst, const musica_ctx* src) {
+    if (dst == src) return;
+    memcpy(dst->rows_expand, src->rows_expand, sizeof(src->rows_expand));
+    memcpy(dst->rows_sdev, src->rows_sdev, sizeof(src->rows_sdev));
+    memcpy(dst->rows_rb, src->rows_rb, sizeof(src->rows_rb));
+}
 
 static uint32_t cnr_scale(int S, int cnrS) { return (uint32_t)ceilf((float)S / (float)cnrS); }  // noise_reduction.comp:38
 
@@ -227,105 +222,6 @@ static int sdev_rows_default(const musica_ctx* c, int i, int batch) {
     return pick_rows(c->sdev_rows, 16, c->lv[i].S, c->lv[i].S, batch);
 }
 
-// How many independent groups the batch is cut into: MUSICA_GROUPS, default 1. Measured on MI355X at
-// 8 x 2048 x 2048 ("Image groups"): 1 group 0.565 ms, 2 groups 0.586 ms, 4 groups 0.78 ms per step —
-// the groups start in lockstep, so their small kernels meet each other instead of the other group's
-// bandwidth-bound ones, and every extra hipGraphLaunch costs ~150 us of host time. Kept as an option for
-// callers whose requests arrive out of phase.
-static int pick_groups(const musica_ctx* c) {
-    if (!c->dag || c->generic || c->B < 2) return 1;
-    int g = env_int("MUSICA_GROUPS", 1);
-    if (g > c->B) g = c->B;
-    return g < 1 ? 1 : g;
-}
-
-static void copy_rows(musica_ctx* dst, const musica_ctx* src) {
-    if (dst == src) return;
-    memcpy(dst->rows_reduce, src->rows_reduce, sizeof(src->rows_reduce));
-    memcpy(dst->rows_band, src->rows_band, sizeof(src->rows_band));
-    memcpy(dst->rows_expand, src->rows_expand, sizeof(src->rows_expand));
-    memcpy(dst->rows_sdev, src->rows_sdev, sizeof(src->rows_sdev));
-    memcpy(dst->rows_rb, src->rows_rb, sizeof(src->rows_rb));
-}
-
-// Shallow copy of the parent restricted to images [i0, i0 + nb): same buffers, pointers moved to the first image.
-static musica_ctx* make_view(const musica_ctx* c, int i0, int nb) {
-    musica_ctx* v = new musica_ctx(*c);
-    v->allocations.clear();   // the parent owns the memory
-    v->spans.clear();
-    v->spans_used = 0;
-    v->views.clear();
-    v->stream = nullptr; v->side = nullptr; v->side1 = nullptr; v->ev_s1 = nullptr; v->ev_s2 = nullptr; v->ev_fork = nullptr; v->ev_join = nullptr; v->ev_gfork = nullptr; v->ev_gdone = nullptr;
-    for (int k = 0; k < kGraphSlots; k++) { v->graph_exec[k] = nullptr; v->graph_input[k] = nullptr; v->graph_used[k] = 0; }   // every group captures and replays its own graphs
-    v->graph_clock = 0;
-    v->first_image = i0;
-    v->B = nb;
-    v->p.batch = (uint32_t)nb;
-    const size_t o = (size_t)i0, NN = (size_t)c->N * c->N;
-    v->d_input += o * NN;
-    v->cur_input = v->d_input;
-    v->d_minmax += o * kMinMaxStride;
-    v->d_mm_slots += o * kMinMaxSlots;
-    v->d_mm_ticket += o * kMinMaxStride;
-    v->d_gr_ticket += o * kGradTicketStride;
-    v->d_norm += o * c->lv[0].plane;
-    for (int i = 0; i < c->L; i++) {
-        v->d_down[i] += o * c->lv[i + 1].plane;
-        v->d_band[i] += o * c->lv[i].plane;
-        v->d_recon[i] += o * c->lv[i].plane;
-        if (i <= MUSICA_CNR_LEVEL) v->d_sdev[i] += o * c->lv[i].plane;
-    }
-    v->d_noise_hist += o * 4 * MUSICA_NOISE_BINS;
-    v->d_noise_max += o * c->L;
-    v->d_curves += o * c->L;
-    v->d_luts += o * MUSICA_COARSER_LEVELS_START;
-    v->d_cnr += o * c->lv[MUSICA_CNR_LEVEL].plane;
-    v->d_grad_hist += o * MUSICA_GRAD_BINS;
-    v->d_grad_hist_b += o * MUSICA_GRAD_BINS;
-    v->d_gzero += o;
-    v->d_thr090 += o;
-    v->d_stats_partial += o * kStatsMaxBlocks;
-    if (v->d_le090) v->d_le090 += o * (size_t)c->lv[1].S * (c->lv[0].S / 8);
-    v->d_grad_max += o;
-    v->d_gcurve += o;
-    v->d_graded += o * c->lv[0].plane;
-    v->d_scratch += o * c->lv[0].plane;
-    v->d_stats += o;
-    if (c->d_clahe_hist) {
-        const size_t tb = (size_t)MUSICA_CLAHE_TILES * MUSICA_CLAHE_TILES * MUSICA_CLAHE_BINS;
-        v->d_clahe_hist += o * tb;
-        v->d_clahe_pts += o * tb;
-        v->d_clahe_graded += o * c->lv[0].plane;
-    }
-    for (int i = 0; i < c->L; i++) {
-        v->rows_reduce[i] = pick_rows(c->reduce_rows, 1, c->lv[i].S, c->lv[i + 1].S, nb);
-        v->rows_band[i] = pick_rows(c->band_rows, 1, c->lv[i].S, c->lv[i + 1].S, nb);
-        v->rows_expand[i] = pick_rows(c->expand_rows, 1, c->lv[i].S, c->lv[i + 1].S, nb);
-        if (i <= MUSICA_CNR_LEVEL) v->rows_sdev[i] = sdev_rows_default(c, i, nb);
-        v->rows_rb[i] = pick_rows(16, 1, c->lv[i].S, c->lv[i + 1].S, nb);
-    }
-    return v;
-}
-
-static bool make_views(musica_ctx* c, int groups) {
-    bool ok = hipEventCreateWithFlags(&c->ev_gfork, hipEventDisableTiming) == hipSuccess;
-    const int per = (c->B + groups - 1) / groups;
-    for (int i0 = 0; i0 < c->B && ok; i0 += per) {
-        musica_ctx* v = make_view(c, i0, c->B - i0 < per ? c->B - i0 : per);
-        c->views.push_back(v);
-        ok = ok && hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipStreamCreateWithFlags(&v->side, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipStreamCreateWithFlags(&v->side1, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&v->ev_s1, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&v->ev_s2, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&v->ev_gdone, hipEventDisableTiming) == hipSuccess;
-        v->cur = v->stream;
-    }
-    return ok;
-}
-
 extern "C" {
 
 uint32_t musica_abi_version(void) { return MUSICA_ABI_VERSION; }
@@ -341,20 +237,6 @@ void musica_destroy(musica_ctx* c) {
     if (!c) return;
     hipSetDevice(c->p.device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    for (musica_ctx* v : c->views) {
-        for (auto& s : v->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
-        if (v->stream) { hipStreamSynchronize(v->stream); hipStreamDestroy(v->stream); }
-        if (v->side) { hipStreamSynchronize(v->side); hipStreamDestroy(v->side); }
-        if (v->side1) { hipStreamSynchronize(v->side1); hipStreamDestroy(v->side1); }
-        if (v->ev_s1) hipEventDestroy(v->ev_s1);
-        if (v->ev_s2) hipEventDestroy(v->ev_s2);
-        if (v->ev_fork) hipEventDestroy(v->ev_fork);
-        if (v->ev_join) hipEventDestroy(v->ev_join);
-        if (v->ev_gdone) hipEventDestroy(v->ev_gdone);
-        for (int k = 0; k < kGraphSlots; k++) if (v->graph_exec[k]) hipGraphExecDestroy(v->graph_exec[k]);
-        delete v;
-    }
-    if (c->ev_gfork) hipEventDestroy(c->ev_gfork);
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     for (int k = 0; k < 2; k++) {
         if (c->ev_copied[k]) hipEventDestroy(c->ev_copied[k]);
@@ -365,9 +247,6 @@ void musica_destroy(musica_ctx* c) {
     if (c->h_out8) hipHostFree(c->h_out8);
     for (int k = 0; k < kGraphSlots; k++) if (c->graph_exec[k]) hipGraphExecDestroy(c->graph_exec[k]);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
-    if (c->side1) { hipStreamSynchronize(c->side1); hipStreamDestroy(c->side1); }
-    if (c->ev_s1) hipEventDestroy(c->ev_s1);
-    if (c->ev_s2) hipEventDestroy(c->ev_s2);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -414,8 +293,7 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->ref_order = (params->flags & MUSICA_FLAG_REFERENCE_ORDER) ? 1 : 0;
     c->generic = (params->flags & MUSICA_FLAG_GENERIC_KERNELS) != 0 || c->ref_order;   // the literal order lives in the one-thread-per-texel kernels
     c->tuning = false;
-    c->stream = nullptr; c->side = nullptr; c->side1 = nullptr; c->ev_s1 = nullptr; c->ev_s2 = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr; c->profiling = 0; c->spans_used = 0; c->cur_input = nullptr;
-    c->ev_gfork = nullptr; c->ev_gdone = nullptr; c->first_image = 0;
+    c->stream = nullptr; c->side = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr; c->profiling = 0; c->spans_used = 0; c->cur_input = nullptr;
     c->d_out8 = nullptr; c->h_out8 = nullptr;
     c->d_input2 = nullptr; c->copy_stream = nullptr; c->ev_copied[0] = c->ev_copied[1] = c->ev_consumed[0] = c->ev_consumed[1] = nullptr;
     memset(c->prof_total_us, 0, sizeof(c->prof_total_us));
@@ -431,11 +309,7 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->hist_cov = (int)(N / 512u) * 512;  // imageSize / histWorkgroupCoverage groups, src/vk_processing.cpp:2293-2295
     for (int i = 0; i < c->L; i++) c->h_cparams[i] = host_contrast_params((uint32_t)i, L);
     for (int i = 0; i < 3; i++) c->h_nr[i] = host_nr_params((uint32_t)i);
-    c->reduce_rows = env_int("MUSICA_REDUCE_ROWS", 16);
-    c->band_trip = env_int("MUSICA_BAND_TRIP", 2);
-    c->expand_trip = env_int("MUSICA_EXPAND_TRIP", 1);
     c->min_waves = 2048;
-    c->band_rows = env_int("MUSICA_BAND_ROWS", 8);
     c->expand_rows = env_int("MUSICA_EXPAND_ROWS", 8);
     c->sdev_rows = env_int("MUSICA_SDEV_ROWS", 32) & ~15;
     if (c->sdev_rows < 16) c->sdev_rows = 16;
@@ -458,12 +332,11 @@ static musica_ctx* create_impl(const musica_params* params) {
     //    0.240 on one stream, 4096^2 L12 0.277 / 0.292 / 0.308);
     //  * one-shot contexts (MUSICA_FLAG_NO_AUTOTUNE | MUSICA_FLAG_NO_GRAPH: musica-standalone): one stream — creating a second one
     //    costs more than one step saves;
-    //  * MUSICA_DAG=1: the three-stream form (enqueue_dag), the default for batches until round 3; never the default now.
+    //  (The three-stream script and the image groups of rounds 1 - 3 won nowhere by more than noise at the end of round 3 and left in round 4.)
     const bool lone = !(params->flags & MUSICA_FLAG_LINEAR);
     const bool one_shot = (params->flags & MUSICA_FLAG_NO_AUTOTUNE) && (params->flags & MUSICA_FLAG_NO_GRAPH);
     const bool small_step = c->B == 1 ? N < 2048 : (size_t)c->B * N * N <= (size_t)3072 * 3072;
-    c->dag = !lone ? 0 : env_int("MUSICA_DAG", (small_step || one_shot) ? 0 : 2);
-    if (c->dag < 0 || c->dag > 2) c->dag = 2;
+    c->dag = !lone ? 0 : (env_int("MUSICA_STREAMS", (small_step || one_shot) ? 1 : 2) >= 2 ? 2 : 0);
     c->use_graph = !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", (lone && (small_step || (c->B == 1 && L >= 11))) ? 0 : 1) != 0;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     if (c->dag) {
@@ -471,17 +344,10 @@ static musica_ctx* create_impl(const musica_params* params) {
         ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     }
-    if (c->dag == 1) {
-        ok = ok && hipStreamCreateWithFlags(&c->side1, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&c->ev_s1, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&c->ev_s2, hipEventDisableTiming) == hipSuccess;
-    }
     for (int k = 0; k < kGraphSlots; k++) { c->graph_exec[k] = nullptr; c->graph_input[k] = nullptr; c->graph_used[k] = 0; }
     c->graph_clock = 0;
-    c->fuse_u16 = env_int("MUSICA_U16", 1) != 0 && (N % 8) == 0 && !c->generic;
+    c->fuse_u16 = (N % 8) == 0 && !c->generic;
     c->norm_valid = false;
-    c->fuse_rb = c->generic ? 0 : env_int("MUSICA_FUSE_RB", 2);
-    if (!c->fuse_u16 && c->fuse_rb == 1) c->fuse_rb = 0;
     // fused gradation histogram: streaming level-0 kernels on raw pixels, cnr scale 8 (every N >= 57 with N % 8 == 0), no CLAHE
     // block (it wants the stored relevant image anyway)
     // (a CLAHE context fuses too since its relevant image comes from the raw pixels, k_relevant4<true>; MUSICA_CLAHE_FUSE=0: as before)
@@ -518,7 +384,7 @@ static musica_ctx* create_impl(const musica_params* params) {
     ok = ok && dalloc(c, &c->d_stats_partial, B * kStatsMaxBlocks);
     ok = ok && dalloc(c, &c->d_plot, (size_t)MUSICA_HIST_RENDER_WIDTH * MUSICA_HIST_RENDER_HEIGHT);
     c->d_le090 = nullptr;
-    if (c->fuse_gh && c->fuse_rb >= 1 && env_int("MUSICA_LE090", 1) != 0) ok = ok && dalloc(c, &c->d_le090, B * (size_t)c->lv[1].S * (c->lv[0].S / 8));
+    if (c->fuse_gh) ok = ok && dalloc(c, &c->d_le090, B * (size_t)c->lv[1].S * (c->lv[0].S / 8));
     ok = ok && dalloc(c, &c->d_grad_max, B);
     ok = ok && dalloc(c, &c->d_gcurve, B);
     ok = ok && dalloc(c, &c->d_graded, B * c->lv[0].plane);
@@ -540,27 +406,12 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->cur_input = c->d_input;
     c->cur = c->stream;
     for (int i = 0; i < c->L; i++) {
-        c->rows_reduce[i] = pick_rows(c->reduce_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
-        c->rows_band[i] = pick_rows(c->band_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
         c->rows_expand[i] = pick_rows(c->expand_rows, 1, c->lv[i].S, c->lv[i + 1].S, c->B);
         if (i <= MUSICA_CNR_LEVEL) c->rows_sdev[i] = sdev_rows_default(c, i, c->B);
         c->rows_rb[i] = pick_rows(env_int("MUSICA_RB_ROWS", 16), 1, c->lv[i].S, c->lv[i + 1].S, c->B);
     }
     const bool tune = !(params->flags & MUSICA_FLAG_NO_AUTOTUNE) && env_int("MUSICA_AUTOTUNE", 1) && !c->generic;
-    const int groups = pick_groups(c);
-    if (groups > 1 && !make_views(c, groups)) {
-        fail("musica_create: stream / event creation for %d image groups failed", groups);
-        musica_destroy(c);
-        return nullptr;
-    }
-    if (tune) {
-        if (c->views.empty()) autotune(c);
-        else {   // the groups launch with their own (smaller) batch: tune that geometry once, share it
-            autotune(c->views[0]);
-            for (musica_ctx* v : c->views) copy_rows(v, c->views[0]);
-            copy_rows(c, c->views[0]);
-        }
-    }
+    if (tune) autotune(c);
     return c;
 }
 
@@ -569,7 +420,7 @@ uint32_t musica_get_levels(const musica_ctx* c) { return c ? (uint32_t)c->L : 0;
 uint32_t musica_get_batch(const musica_ctx* c) { return c ? (uint32_t)c->B : 0; }
 int musica_get_dispatch(const musica_ctx* c, int* streams, int* graph) {
     if (!c) return 0;
-    if (streams) *streams = c->dag == 0 ? 1 : c->dag == 2 ? 2 : 3;
+    if (streams) *streams = c->dag == 0 ? 1 : 2;
     if (graph) *graph = c->use_graph ? 1 : 0;
     return 1;
 }
@@ -603,16 +454,6 @@ struct Span {
 };
 
 static void collect_spans(musica_ctx* c) {
-    for (musica_ctx* v : c->views) {   // the groups' spans are accounted to the parent
-        for (size_t i = 0; i < v->spans_used; i++) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, v->spans[i].a, v->spans[i].b) == hipSuccess) {
-                c->prof_total_us[v->spans[i].id] += (double)ms * 1000.0;
-                c->prof_count[v->spans[i].id] += 1;
-            }
-        }
-        v->spans_used = 0;
-    }
     for (size_t i = 0; i < c->spans_used; i++) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->spans[i].a, c->spans[i].b) == hipSuccess) {
@@ -648,36 +489,19 @@ static void ensure_normalized(musica_ctx* c) {
     c->norm_valid = true;
 }
 
-static void run_reduce_level(musica_ctx* c, int i, int rows) {
-    if (i == 0 && c->fuse_u16) {
-        launch_reduce_u16(c->cur, c->cur_input, c->lv[0], c->d_down[0], c->lv[1], c->B, rows, c->d_minmax, c->min_chain_exact);
-        return;
-    }
-    launch_reduce(c->cur, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, c->generic, i == 0 ? 0 : 1, c->ref_order);   // one fixed tile shape: `rows` only steers the uint16 form
-}
-// reduce + band of a level in one launch
-static bool rb_level(const musica_ctx* c, int i) {
-    if (c->generic || c->lv[i].S < 8 || (c->lv[i].S % 8) != 0) return false;
-    return i == 0 ? (c->fuse_rb >= 1 && (c->fuse_u16 || c->fuse_rb >= 2)) : c->fuse_rb >= 2;
-}
+// reduce + band of a level in one launch: every level whose side is a multiple of 8 (level 0 then reads the raw pixels)
+static bool rb_level(const musica_ctx* c, int i) { return !c->generic && c->lv[i].S >= 8 && (c->lv[i].S % 8) == 0; }
 static void run_reduce_band(musica_ctx* c, int i, int rows) {
-    if (i == 0 && c->fuse_u16)
+    if (i == 0)
         launch_reduce_band_u16(c->cur, c->cur_input, c->d_down[0], c->d_band[0], c->lv[0], c->lv[1], c->B, rows, c->d_minmax, c->min_chain_exact, c->d_le090);
     else
         launch_reduce_band(c->cur, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, rows);
 }
-static void run_band_level(musica_ctx* c, int i, int rows) {
-    if (i == 0 && c->fuse_u16) {
-        launch_band_u16(c->cur, c->cur_input, c->d_down[0], c->d_band[0], c->lv[0], c->lv[1], c->B, rows, c->band_trip, c->d_minmax, c->min_chain_exact);
-        return;
-    }
-    launch_band(c->cur, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, rows, c->generic, c->band_trip, c->ref_order);
-}
-// reduce and band of level i, as one launch where that form applies
+// reduce and band of level i, as one launch where that form applies, else the one-thread-per-texel kernels
 static void run_reduce_and_band(musica_ctx* c, int i) {
     if (rb_level(c, i)) { Span sp(c, i == 0 ? MUSICA_KERNEL_REDUCE_L0 : MUSICA_KERNEL_REDUCE_REST); run_reduce_band(c, i, c->rows_rb[i]); return; }
-    { Span sp(c, i == 0 ? MUSICA_KERNEL_REDUCE_L0 : MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, i, c->rows_reduce[i]); }
-    { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
+    { Span sp(c, i == 0 ? MUSICA_KERNEL_REDUCE_L0 : MUSICA_KERNEL_REDUCE_REST); launch_reduce(c->cur, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, true, i == 0 ? 0 : 1, c->ref_order); }
+    { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); launch_band(c->cur, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, c->ref_order); }
 }
 static void run_sdev_level(musica_ctx* c, int i, int rows) {
     if (c->ref_order) {   // img_sdev.comp literally, then noise_hist.comp on the stored image
@@ -813,7 +637,7 @@ static void run_expand_level_h(musica_ctx* c, int lvl, int rows, bool with_hist)
         a.le090 = c->d_le090;
         if (clahe_hist_in_expand(c, rows)) a.chist = c->d_clahe_hist;
     }
-    launch_expand(c->cur, a, gain_mode(lvl), uses_nr(lvl), c->B, c->generic, c->expand_trip);
+    launch_expand(c->cur, a, gain_mode(lvl), uses_nr(lvl), c->B, c->generic);
 }
 static void run_expand_level(musica_ctx* c, int lvl, int rows) { run_expand_level_h(c, lvl, rows, true); }
 
@@ -828,23 +652,15 @@ static void enqueue_expand(musica_ctx* c, bool with_hist, int top = -1 /* first 
 // stage "grad" (src/vk_processing.cpp:2456-2518)
 // fused: the level-0 expand launch has already accumulated the histogram (run_expand_level_h with_hist); what is left of K18 + K19 is
 // the literal recount of images that hold an exact zero (a launch that returns at once for every other image).
-// beside: the three-stream form runs the CLAHE block (it reads the reconstruction and feeds nothing of this step) on the side stream,
-// next to the gradation chain (histogram recount, curve, apply), instead of in front of it
-static void enqueue_gradation(musica_ctx* c, bool fused, bool beside = false) {
+static void enqueue_gradation(musica_ctx* c, bool fused) {
     fused = fused && c->fuse_gh && !c->generic;
     const LevelDesc& l0 = c->lv[0];
     const LevelDesc& l3 = c->lv[MUSICA_CNR_LEVEL];
     const int scale = (int)cnr_scale(l0.S, l3.S);
     const bool ch_done = fused && clahe_hist_in_expand(c, c->rows_expand[0]);   // the level-0 expand launch counted the CLAHE histogram
     const bool one_apply = c->d_clahe_hist && c->clahe_raw && !c->generic && (l0.S % 4) == 0 && c->clahe_one_apply;   // both curves in one pass
-    beside = beside && c->d_clahe_hist && c->side && c->clahe_raw && !(one_apply && ch_done);   // (16 curve workgroups are not worth a join)
     if (c->d_clahe_hist) {  // #ifdef ENABLE_CLAHE block, src/vk_processing.cpp:2471-2489
         hipStream_t cs = c->stream;
-        if (beside) {
-            hipEventRecord(c->ev_fork, c->stream);       // both events have done their duty earlier in the step
-            hipStreamWaitEvent(c->side, c->ev_fork, 0);
-            cs = c->side;
-        }
         if (c->clahe_raw) {   // relevance computed inside the histogram launch from the raw pixels: no relevant image on the hot path
             launch_clahe(cs, c->d_recon[0], nullptr, c->d_clahe_graded, l0, c->d_clahe_hist, c->d_clahe_pts, c->B, c->cur_input, c->d_thr090, c->d_cnr, &l3, scale,
                          ch_done, !one_apply);
@@ -852,7 +668,6 @@ static void enqueue_gradation(musica_ctx* c, bool fused, bool beside = false) {
             launch_relevant(cs, c->d_norm, c->d_cnr, c->d_scratch, l0, l3, scale, c->B);
             launch_clahe(cs, c->d_recon[0], c->d_scratch, c->d_clahe_graded, l0, c->d_clahe_hist, c->d_clahe_pts, c->B);
         }
-        if (beside) hipEventRecord(c->ev_join, c->side);
     }
     GradArgs g;
     g.img = c->d_recon[0]; g.normalized = c->d_norm; g.cnr = c->d_cnr; g.hist = fused ? c->d_grad_hist_b : c->d_grad_hist;
@@ -872,84 +687,11 @@ static void enqueue_gradation(musica_ctx* c, bool fused, bool beside = false) {
         launch_grad_curve(c->stream, c->d_grad_hist, c->d_grad_max, c->d_gcurve, c->B, fused ? c->d_grad_hist_b : nullptr, fused ? c->d_gzero : nullptr);
     }
     if (one_apply) {
-        if (beside) hipStreamWaitEvent(c->stream, c->ev_join, 0);
         Span sp(c, MUSICA_KERNEL_GRAD_APPLY);
         launch_grad_clahe_apply(c->stream, c->d_recon[0], c->d_clahe_graded, c->d_graded, l0, c->d_clahe_pts, c->d_gcurve, c->B);
         return;
     }
     { Span sp(c, MUSICA_KERNEL_GRAD_APPLY); launch_grad_apply(c->stream, c->d_recon[0], c->d_graded, l0, c->d_gcurve, c->B); }
-    if (beside) hipStreamWaitEvent(c->stream, c->ev_join, 0);
-}
-
-// Three-stream form of the dispatch script (dag == 1, the default for batches and large images). The reference submits
-// everything to one in-order queue; the data dependences allow more:
-//   stream : minmax (+ clears) R0 R1 | B0 S0 B1 S1 (wait side, side1) curves E2 E1 E0 gradation
-//   side   :                         | R2 .. R(L-1) B2 B3 . B4 .. E(L-1) .. E4 S3 E3
-//   side1  :                                    (B2) S2
-// Small kernels only get wave slots in the tails of a chip-filling kernel beside them (rocprofv3 timeline: a 6 us reduce waits
-// 30 us behind band 0; sdev 2 and sdev 3 sit out sdev 0, whose 4096 wavefronts hold every slot for the whole launch), so the
-// order on the side streams is chosen to have as little as possible left when sdev 0 ends: first everything that reads neither a
-// histogram nor an sdev image — the reduce chain, the band-pass images, the constant-gain expand slots above level 3 — then
-// sdev 3 behind them and sdev 2 on a third stream as soon as band 2 exists (20 us kernels: a wavefront walks a 16-row run row
-// by row); they end up under band 1 / sdev 1 instead of in front of the curves (-10 us per step against sdev 2 / sdev 3 in
-// the side chain, where ~100 us of small launches still followed them). Same kernels, same arguments, same results.
-// Issue order = capture order: a graph replay enqueues its nodes in capture order, a few microseconds each, so the main
-// stream's kernels are captured before the side chains (with the side chains first, band 0 started 45 us late).
-// Measured and not kept (same box, A/B): level 1 ahead of level 0 on the main stream with the curves of levels >= 1 and
-// expand 3 / 2 / 1 on a side stream beside the level-0 kernels (0.528 - 0.538 ms against 0.518 - 0.527: the side work still
-// only runs once sdev 0 drains, and hipGraph maps the extra branches onto fewer queues than captured); a high-priority side
-// stream (no effect); CU-masked streams (32 / 224 CU split: 5 % slower); dynamic-LDS padding of the level-0 launches to keep
-// a workgroup slot per CU free (no effect on the waiting kernels); one launch for band 0 + band 1 and one for sdev 0 + sdev 1
-// (-11 us of kernel time but no change of the step: the side chain was the critical path); the first one, two or all reduce
-// launches of the side chain on the main stream ahead of the fork (within +-1 %); one 1024-thread workgroup per
-// image for the whole tail of levels >= 3 (bit-exact, but 153 us for one image — a single CU walks it row by row — against
-// ~100 us for the ten launches it replaces).
-static void enqueue_dag(musica_ctx* c) {
-    c->cur = c->stream;
-    enqueue_norm(c, true);   // with the clears of :2153-2162
-    // reduce (+ band, where the fused march applies: k_reduce_band) of levels 0 and 1
-    const bool rb0 = rb_level(c, 0), rb1 = rb_level(c, 1);
-    if (rb0) { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_band(c, 0, c->rows_rb[0]); }
-    else { Span sp(c, MUSICA_KERNEL_REDUCE_L0); run_reduce_level(c, 0, c->rows_reduce[0]); }
-    if (rb1) { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_band(c, 1, c->rows_rb[1]); }
-    else { Span sp(c, MUSICA_KERNEL_REDUCE_REST); run_reduce_level(c, 1, c->rows_reduce[1]); }
-    hipEventRecord(c->ev_fork, c->stream);
-    hipStreamWaitEvent(c->side, c->ev_fork, 0);
-    c->cur = c->stream;
-    for (int i = 0; i < 2; i++) {
-        if (!(i == 0 ? rb0 : rb1)) { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); run_band_level(c, i, c->rows_band[i]); }
-        { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, i, c->rows_sdev[i]); }
-    }
-    c->cur = c->side;
-    for (int i = 2; i <= MUSICA_CNR_LEVEL; i++) run_reduce_and_band(c, i);
-    hipEventRecord(c->ev_s2, c->side);   // band 2 (and 3) exist
-    hipStreamWaitEvent(c->side1, c->ev_s2, 0);
-    c->cur = c->side1;
-    { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, 2, c->rows_sdev[2]); }
-    hipEventRecord(c->ev_s1, c->side1);
-    c->cur = c->side;
-    const int T = enqueue_reduce_from(c, MUSICA_CNR_LEVEL + 1);
-    for (int lvl = T - 1; lvl > MUSICA_CNR_LEVEL; lvl--) {
-        Span sp(c, MUSICA_KERNEL_EXPAND_REST);
-        run_expand_level(c, lvl, c->rows_expand[lvl]);
-    }
-    { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_level(c, MUSICA_CNR_LEVEL, c->rows_sdev[MUSICA_CNR_LEVEL]); }
-    // expand 3 reads no curve (two-point constant gain, GAIN_RANGE) and no cnr: it stays in the side chain, off the main stream's tail
-    { Span sp(c, MUSICA_KERNEL_EXPAND_REST); run_expand_level(c, MUSICA_CNR_LEVEL, c->rows_expand[MUSICA_CNR_LEVEL]); }
-    hipEventRecord(c->ev_join, c->side);
-    c->cur = c->stream;
-    hipStreamWaitEvent(c->stream, c->ev_s1, 0);
-    hipStreamWaitEvent(c->stream, c->ev_join, 0);
-    {   // curves of every level + cnr of level 3 in one launch (kernels_analysis.hip k_curves_cnr)
-        Span sp(c, MUSICA_KERNEL_CURVES);
-        launch_curves_cnr(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
-                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_thr090);
-    }
-    for (int lvl = MUSICA_CNR_LEVEL - 1; lvl >= 0; lvl--) {
-        Span sp(c, lvl == 0 ? MUSICA_KERNEL_EXPAND_L0 : MUSICA_KERNEL_EXPAND_REST);
-        run_expand_level(c, lvl, c->rows_expand[lvl]);
-    }
-    enqueue_gradation(c, true, true);
 }
 
 // One in-order stream, the order of the reference's command buffer (dag == 0).
@@ -989,12 +731,11 @@ static void enqueue_fork(musica_ctx* c) {
     enqueue_gradation(c, true);
 }
 static void enqueue_script(musica_ctx* c) {
-    if (c->dag == 2) enqueue_fork(c);
-    else if (c->dag) enqueue_dag(c);
+    if (c->dag) enqueue_fork(c);
     else enqueue_linear(c);
 }
 
-// Captures enqueue_dag() (both streams: the side stream joins the capture through ev_fork and rejoins
+// Captures the dispatch script (with two streams the side stream joins the capture through ev_fork and rejoins
 // through ev_join) into an executable graph for the current input pointer.
 static int capture_graph(musica_ctx* c) {
     int k = 0;   // an empty slot, else the least recently used one
@@ -1020,34 +761,7 @@ static int capture_graph(musica_ctx* c) {
     return k;
 }
 
-static int enqueue_all(musica_ctx* c);
-
-// The batch as image groups: every group is an independent pipeline on its own pair of streams (its own graph
-// replay), forked from and joined back into the parent's stream with plain events. The fork / join stays outside
-// the captures on purpose: a capture whose forked streams fork again sends hipStreamEndCapture of the ROCm 7.0
-// runtime (the one PyTorch ships and loads first) into unbounded recursion.
-// With per-kernel profiling on, the groups run one after the other so that a bracketed kernel is alone on the chip.
-static int enqueue_groups(musica_ctx* c) {
-    hipEventRecord(c->ev_gfork, c->stream);
-    const musica_ctx* prev = nullptr;
-    for (musica_ctx* v : c->views) {
-        v->cur_input = c->cur_input + (size_t)v->first_image * c->N * c->N;
-        v->profiling = c->profiling;
-        hipStreamWaitEvent(v->stream, c->ev_gfork, 0);
-        if (c->profiling && prev) hipStreamWaitEvent(v->stream, prev->ev_gdone, 0);
-        if (!enqueue_all(v)) return 0;
-        hipEventRecord(v->ev_gdone, v->stream);
-        prev = v;
-    }
-    for (musica_ctx* v : c->views) hipStreamWaitEvent(c->stream, v->ev_gdone, 0);
-    c->norm_valid = c->views[0]->norm_valid;
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail("group dispatch failed: %s", hipGetErrorString(e));
-    return 1;
-}
-
 static int enqueue_all(musica_ctx* c) {
-    if (!c->views.empty() && !c->tuning) return enqueue_groups(c);
     if (!c->tuning && c->use_graph && c->profiling == 0) {
         int k = -1;
         for (int j = 0; j < kGraphSlots; j++)
@@ -1112,16 +826,13 @@ static void autotune(musica_ctx* c) {
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
     c->tuning = true;
     const int reps = 3;
-    static const int cand_reduce[] = {4, 8, 12, 16, 32};
     static const int cand_pair[] = {2, 4, 8, 16};   // band / expand count coarse rows (two fine rows each)
     static const int cand_sdev[] = {0, 16, 32, 64};   // 0: one run per workgroup
     for (int i = 0; i < c->L; i++) {
         if (c->lv[i].S < 512 || (c->lv[i].S % 8) != 0) continue;   // small levels are launch-bound: keep the heuristic
         static const int cand_rb[] = {4, 8, 16, 32, 64};
-        struct { int* slot; const int* cand; int ncand; void (*fn)(musica_ctx*, int, int); bool use; } jobs[5] = {
+        struct { int* slot; const int* cand; int ncand; void (*fn)(musica_ctx*, int, int); bool use; } jobs[3] = {
             {&c->rows_rb[i], cand_rb, 5, run_reduce_band, rb_level(c, i)},
-            {&c->rows_reduce[i], cand_reduce, 5, run_reduce_level, !rb_level(c, i) && i == 0 && c->fuse_u16},
-            {&c->rows_band[i], cand_pair, 4, run_band_level, !rb_level(c, i)},
             {&c->rows_expand[i], cand_pair, 4, run_expand_level, true},
             {i <= MUSICA_CNR_LEVEL ? &c->rows_sdev[i] : nullptr, cand_sdev, 4, run_sdev_level, i <= MUSICA_CNR_LEVEL},
         };
@@ -1210,7 +921,6 @@ int musica_execute(musica_ctx* c, const uint16_t* pixels) {
 int musica_execute_stream(musica_ctx* c, const uint16_t* const* pixels, uint32_t count, musica_stats* stats) {
     CHECK_CTX(c);
     if (!pixels) return fail("musica_execute_stream: pixels is NULL");
-    if (!c->views.empty()) return fail("musica_execute_stream: not available with image groups (MUSICA_GROUPS > 1)");
     const size_t bytes = (size_t)c->B * c->N * c->N * sizeof(uint16_t);
     if (!c->d_input2) {
         if (!dalloc(c, &c->d_input2, (size_t)c->B * c->N * c->N)) return fail("musica_execute_stream: device allocation failed");
@@ -1396,8 +1106,8 @@ static const uint8_t* out_pixels_pinned(musica_ctx* c, uint32_t idx) {
     const uint32_t N = (uint32_t)c->N, margin = MUSICA_OUT_MARGIN;
     if (N <= 2 * margin) { fail("saveOutImage: image too small for the %u-pixel margin", margin); return nullptr; }
     const size_t nw = N - 2 * margin, bytes = nw * nw;
-    if (!c->d_out8) {
-        if (!dalloc(c, &c->d_out8, bytes)) { fail("saveOutImage: device allocation failed"); return nullptr; }
+    if (!c->h_out8) {   // keyed on the LAST resource of the block: a call that failed half-way is retried, never half-initialised
+        if (!c->d_out8 && !dalloc(c, &c->d_out8, bytes)) { fail("saveOutImage: device allocation failed"); return nullptr; }
         if (hipHostMalloc((void**)&c->h_out8, bytes, hipHostMallocDefault) != hipSuccess) { c->h_out8 = nullptr; fail("saveOutImage: pinned allocation failed"); return nullptr; }
     }
     launch_out_pixels(c->stream, c->d_graded + (size_t)idx * c->lv[0].plane, c->lv[0], (int)margin, c->d_out8);
@@ -1408,6 +1118,7 @@ static const uint8_t* out_pixels_pinned(musica_ctx* c, uint32_t idx) {
 }
 
 int musica_get_out_pixels(musica_ctx* c, uint32_t idx, uint8_t* dst) {
+    ABI_TRY
     CHECK_CTX(c); CHECK_IMG(c, idx);
     if (!dst) return fail("musica_get_out_pixels: dst is NULL");
     const uint8_t* px = out_pixels_pinned(c, idx);
@@ -1415,9 +1126,11 @@ int musica_get_out_pixels(musica_ctx* c, uint32_t idx, uint8_t* dst) {
     const size_t nw = (size_t)c->N - 2 * MUSICA_OUT_MARGIN;
     memcpy(dst, px, nw * nw);
     return 1;
+    ABI_CATCH("musica_get_out_pixels")
 }
 
 int musica_save_out_image(musica_ctx* c, uint32_t idx, const char* path) {
+    ABI_TRY
     CHECK_CTX(c); CHECK_IMG(c, idx);
     if (!path) return fail("musica_save_out_image: path is NULL");
     const uint8_t* px = out_pixels_pinned(c, idx);
@@ -1425,6 +1138,7 @@ int musica_save_out_image(musica_ctx* c, uint32_t idx, const char* path) {
     const uint32_t nw = (uint32_t)c->N - 2 * MUSICA_OUT_MARGIN;
     if (!musica_write_bmp_gray(path, nw, nw, px)) return fail("failed to write out file");  // :2636-2642
     return 1;
+    ABI_CATCH("musica_save_out_image")
 }
 
 int musica_get_noise_hist(musica_ctx* c, uint32_t idx, uint32_t level, uint32_t* dst) {
@@ -1633,7 +1347,6 @@ int musica_profile_reset(musica_ctx* c) {
     CHECK_CTX(c);
     HIP_OK(hipStreamSynchronize(c->stream));
     c->spans_used = 0;
-    for (musica_ctx* v : c->views) v->spans_used = 0;
     memset(c->prof_total_us, 0, sizeof(c->prof_total_us));
     memset(c->prof_count, 0, sizeof(c->prof_count));
     return 1;

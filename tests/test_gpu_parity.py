@@ -83,14 +83,14 @@ def _compare_all(p, o, ob, idx=0, tag=""):
 CASES = [(512, 4, 1), (512, 0, 2), (256, 0, 3), (200, 5, 4), (1000, 6, 5), (333, 0, 6), (1024, 6, 7), (2048, 6, 8), (1792, 0, 9)]
 
 
-@pytest.mark.parametrize("dispatch", ["default", "graph3"])
+@pytest.mark.parametrize("dispatch", ["default", "graph2"])
 @pytest.mark.parametrize("n,levels,seed", CASES)
 def test_pipeline_bit_exact_vs_fast_oracle(ob, n, levels, seed, dispatch, monkeypatch):
     # "default": what musica_create picks for a lone context of this size (one image up to 3072^2: eager launches on one
-    # stream); "graph3": the captured three-stream graph that larger steps replay
-    if dispatch == "graph3":
+    # stream); "graph2": the captured two-stream graph that larger steps replay
+    if dispatch == "graph2":
         monkeypatch.setenv("MUSICA_GRAPH", "1")
-        monkeypatch.setenv("MUSICA_DAG", "1")
+        monkeypatch.setenv("MUSICA_STREAMS", "2")
     px = phantom(n, seed)
     o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px)
     p = _proc(n, levels)
@@ -138,48 +138,11 @@ def test_resident_input_entry_point(ob):
     p.cleanup()
 
 
-@pytest.mark.parametrize("flags", [0, mp.FLAG_CLAHE, mp.FLAG_NO_GRAPH])
-def test_image_groups_give_the_same_bits(ob, flags, monkeypatch):
-    """The batch cut into concurrently running groups (uneven: 5 images -> 2 + 2 + 1) equals the single-group
-    run bit for bit, every getter addresses the right image, and per-kernel profiling still counts every launch."""
-    n, levels, b = 520, 5, 5
-    px = np.stack([phantom(n, 500 + k) for k in range(b)])
-    monkeypatch.setenv("MUSICA_DAG", "1")      # image groups are a feature of the three-stream form (a batch this small defaults to one stream)
-    monkeypatch.setenv("MUSICA_GRAPH", "1")
-    monkeypatch.setenv("MUSICA_GROUPS", "1")
-    one = _proc(n, levels, batch=b, flags=flags)
-    monkeypatch.setenv("MUSICA_GROUPS", "3")
-    grp = _proc(n, levels, batch=b, flags=flags)
-    for rep in range(2):
-        assert one.execute(px) and grp.execute(px)
-        _same(one.graded(), grp.graded(), "graded (groups vs one)")
-    for k in (0, 2, 4):
-        o = ob.Oracle(n, levels, ob.ORDER_FAST, flags & 1).execute(px[k])
-        _compare_all(grp, o, ob, idx=k, tag="group image %d: " % k)
-        if flags & mp.FLAG_CLAHE:
-            _same(grp.image(mp.IMG_CLAHE_GRADED, 0, k), o.image(ob.IMG_CLAHE_GRADED), "clahe graded %d" % k)
-    grp.profile_enable(True)
-    assert grp.execute(px)
-    grp.profile_enable(False)
-    prof = grp.profile()
-    assert prof["reduce_l0"][1] == 3 and prof["grad_apply"][1] == 3      # one launch per group
-    _same(one.graded(), grp.graded(), "graded (groups, profiling)")
-    d = grp.device_alloc(px.nbytes)
-    grp.h2d(d, px[::-1].copy())
-    assert grp.execute_device(d)
-    grp.sync()
-    assert one.execute(px[::-1].copy())
-    _same(one.graded(), grp.graded(), "graded (groups, caller-owned input)")
-    grp.device_free(d)
-    one.cleanup()
-    grp.cleanup()
-
-
 def test_default_dispatch_per_workload(monkeypatch):
     """What musica_create picks when nothing overrides it: one image below 2048^2 and batches of up to 3072^2
     texels: one stream, eager; everything larger: two streams, graph replay (eager for one image with 11 or more levels); pipeline
     contexts (MUSICA_FLAG_LINEAR): one stream + graph; one-shot contexts (the CLI's flags): one stream, eager."""
-    for v in ("MUSICA_DAG", "MUSICA_GRAPH"):
+    for v in ("MUSICA_STREAMS", "MUSICA_GRAPH"):
         monkeypatch.delenv(v, raising=False)
     cases = [((512, 4, 1, 0), (1, False)), ((1024, 5, 4, 0), (1, False)), ((2048, 6, 1, 0), (2, True)), ((2048, 0, 1, 0), (2, False)),
              ((2048, 6, 8, 0), (2, True)), ((2048, 6, 2, 0), (1, False)), ((2048, 0, 8, 0), (2, True)), ((2048, 6, 8, mp.FLAG_LINEAR), (1, True)), ((2048, 6, 1, mp.FLAG_NO_AUTOTUNE | mp.FLAG_NO_GRAPH), (1, False)),
@@ -192,18 +155,18 @@ def test_default_dispatch_per_workload(monkeypatch):
 
 @pytest.mark.parametrize("batch", [1, 3])
 def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
-    """MUSICA_DAG = 0 (one in-order stream, the reference's order), 1 (three streams) and 2 (two streams: the analysis beside the
+    """MUSICA_STREAMS = 1 (one in-order stream, the reference's order) and 2 (two streams: the analysis beside the
     reduce tail), graph replay and eager: every form against the oracle, twice in a row (histograms re-cleared, events re-armed),
     and musica_get_dispatch reports the form."""
     n, levels = 1032, 6
     px = np.stack([phantom(n, 800 + k) for k in range(batch)])
     want = [ob.Oracle(n, levels, ob.ORDER_FAST).execute(px[k]) for k in range(batch)]
-    for dag in ("0", "1", "2"):
+    for dag in ("1", "2"):
         for flags, graph in ((0, "1"), (mp.FLAG_NO_GRAPH, "1"), (0, "0")):
-            monkeypatch.setenv("MUSICA_DAG", dag)
+            monkeypatch.setenv("MUSICA_STREAMS", dag)
             monkeypatch.setenv("MUSICA_GRAPH", graph)
             p = _proc(n, levels, batch=batch, flags=flags)
-            assert p.dispatch() == ({"0": 1, "1": 3, "2": 2}[dag], flags == 0 and graph == "1")
+            assert p.dispatch() == (int(dag), flags == 0 and graph == "1")
             for rep in range(2):
                 assert p.execute(px)
             for k in range(batch):
@@ -211,16 +174,15 @@ def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
             p.cleanup()
 
 
-@pytest.mark.parametrize("env", [{"MUSICA_BAND_TRIP": "1"}, {"MUSICA_EXPAND_TRIP": "2"}, {"MUSICA_U16": "0"}, {"MUSICA_FUSE_GH": "0"}, {"MUSICA_FUSE_RB": "0"}, {"MUSICA_FUSE_RB": "1"}, {"MUSICA_LE090": "0"}, {"MUSICA_XCD_SWIZZLE": "0"}, {"MUSICA_GRAD_ONE_LAUNCH": "0"}, {"MUSICA_TINY_TAIL": "0"},
+@pytest.mark.parametrize("env", [{"MUSICA_FUSE_GH": "0"}, {"MUSICA_XCD_SWIZZLE": "0"}, {"MUSICA_GRAD_ONE_LAUNCH": "0"}, {"MUSICA_TINY_TAIL": "0"},
                                  {"MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "0"}, {"MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "1"},
-                                 {"MUSICA_FUSE_RB": "2", "MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "4"}, {"MUSICA_FUSE_RB": "2", "MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "64"},
-                                 {"MUSICA_FUSE_GH": "1", "MUSICA_EXPAND_TRIP": "2"},
-                                 {"MUSICA_AUTOTUNE": "0", "MUSICA_REDUCE_ROWS": "4", "MUSICA_BAND_ROWS": "2", "MUSICA_EXPAND_ROWS": "2", "MUSICA_SDEV_ROWS": "16"},
-                                 {"MUSICA_AUTOTUNE": "0", "MUSICA_REDUCE_ROWS": "32", "MUSICA_BAND_ROWS": "16", "MUSICA_EXPAND_ROWS": "16", "MUSICA_SDEV_ROWS": "64", "MUSICA_SDEV_RUN": "0"}],
+                                 {"MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "1"}, {"MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "3"}, {"MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "4"}, {"MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "64"},
+                                 {"MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "5", "MUSICA_EXPAND_ROWS": "2", "MUSICA_SDEV_ROWS": "16"},
+                                 {"MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "32", "MUSICA_EXPAND_ROWS": "16", "MUSICA_SDEV_ROWS": "64", "MUSICA_SDEV_RUN": "0"}],
                          ids=lambda e: ",".join("%s=%s" % (k[7:], v) for k, v in e.items()))
 def test_kernel_variants_and_launch_geometries_give_the_same_bits(ob, env, monkeypatch):
-    """The alternative forms of the streaming kernels kept in the library (rows-per-trip of band / expand, stored
-    normalized image) and extreme rows-per-wavefront choices: all bit-identical to the oracle."""
+    """The fallback forms the library keeps because some context needs them anyway (separate gradation histogram, plain tile mapping,
+    one launch per tail level, both sdev forms) and extreme / odd rows-per-wavefront choices: all bit-identical to the oracle."""
     n, levels = 1024, 6
     px = phantom(n, 900)
     o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(px)
@@ -232,7 +194,7 @@ def test_kernel_variants_and_launch_geometries_give_the_same_bits(ob, env, monke
     p.cleanup()
 
 
-@pytest.mark.parametrize("dag,one_launch", [("0", "1"), ("1", "1"), ("2", "1"), ("0", "0")])
+@pytest.mark.parametrize("dag,one_launch", [("1", "1"), ("2", "1"), ("1", "0")])
 def test_exact_zeros_in_the_reconstruction_take_the_literal_histogram(ob, dag, one_launch, monkeypatch):
     """A collimated image (test/metamorphic_test/script.py's collimator alteration blacks out a frame): raw zeros give
     normalized 0, band 0 and — far enough inside — a reconstruction that is exactly 0, where the reference's histogram
@@ -241,7 +203,7 @@ def test_exact_zeros_in_the_reconstruction_take_the_literal_histogram(ob, dag, o
     without zeros keeps the fused count. Frame edges are not multiples of 16, so areas with texels on both sides exist.
     The recount and the tone curve are one launch (k_grad_recount_curve: 64 workgroups recount, the one that draws the last ticket
     builds the curve; three executes in a row: the tickets re-arm); MUSICA_GRAD_ONE_LAUNCH=0 is the two-launch form."""
-    monkeypatch.setenv("MUSICA_DAG", dag)
+    monkeypatch.setenv("MUSICA_STREAMS", dag)
     monkeypatch.setenv("MUSICA_GRAD_ONE_LAUNCH", one_launch)
     n, levels = 1024, 4
     a = phantom(n, 61)
@@ -752,7 +714,7 @@ def test_tiny_tail_of_a_full_depth_pyramid_in_one_launch(ob, n, levels, batch, t
     is one launch per level and stage. Every image of every level equals the oracle either way."""
     monkeypatch.setenv("MUSICA_TINY_TAIL", tail)
     if dag is not None:
-        monkeypatch.setenv("MUSICA_DAG", dag)
+        monkeypatch.setenv("MUSICA_STREAMS", dag)
     px = np.stack([phantom(n, 40 + k) for k in range(batch)])
     p = _proc(n, levels, batch=batch)
     p.upload(px)
