@@ -17,7 +17,12 @@ flags = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 p = mp.MusicaProcessing()
 assert p.init(n, levels=L, batch=b, flags=flags | mp.FLAG_LINEAR | (mp.FLAG_NO_AUTOTUNE if os.environ.get("PROBE_TUNE", "0") == "0" else 0))
 p.upload(np.stack([phantom(n, 100 + k) for k in range(b)]))
+idle = float(os.environ.get("PROBE_IDLE_MS", "0"))   # > 0: drain the device and sleep between steps (every step starts on an idle memory system)
+import time
 for _ in range(40):
     p.execute_device()
+    if idle > 0:
+        p.sync()
+        time.sleep(idle / 1e3)
 p.sync()
 p.cleanup()

@@ -68,8 +68,8 @@ static void run(const char* name, Set* s, int NB, float* sink, size_t px, hipStr
 
 int main(int argc, char** argv) {
     const size_t px = (size_t)(argc > 1 ? atoi(argv[1]) : 8) * 2048 * 2048;
-    const int NB = 3;
-    Set s[NB];
+    const int NB = argc > 2 ? atoi(argv[2]) : 3;   // buffer sets rotated over (8 x (67 + 134 + ...) MB: beyond the Infinity Cache for every stream)
+    Set s[16];
     for (int k = 0; k < NB; k++) {
         CK(hipMalloc(&s[k].u, px * 2)); CK(hipMalloc(&s[k].a, px * 4)); CK(hipMalloc(&s[k].b, px * 4)); CK(hipMalloc(&s[k].c, px)); CK(hipMalloc(&s[k].o, px * 4)); CK(hipMalloc(&s[k].oc, px));
         CK(hipMemset(s[k].u, 0x11, px * 2)); CK(hipMemset(s[k].a, 0x3c, px * 4)); CK(hipMemset(s[k].b, 0x3c, px * 4)); CK(hipMemset(s[k].c, 0x3c, px));
@@ -78,6 +78,11 @@ int main(int argc, char** argv) {
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     printf("pixels per launch: %zu\n", px);
+    if (argc > 3) {   // reads only
+        run<1, 0>("read u16 only (r2)", s, NB, sink, px, st, a, b, 2.0);
+        run<2, 0>("read f32 only (r4)", s, NB, sink, px, st, a, b, 4.0);
+        return 0;
+    }
     run<1 | 16 | 32, 0>("rb0 (r2 w4+1)", s, NB, sink, px, st, a, b, 7.0);
     run<1 | 16 | 32, 1>("rb0 (r2 w4+1)", s, NB, sink, px, st, a, b, 7.0);
     run<2 | 16, 0>("sdev / apply (r4 w4)", s, NB, sink, px, st, a, b, 8.0);

@@ -735,10 +735,11 @@ void launch_minmax(hipStream_t st, const uint16_t* px, int N, uint32_t* minmax, 
     // one trip of kMinMaxLoads loads per lane (2048^2: 64 blocks of 128 KiB) up to 512 blocks per image, then more trips: a block
     // ends with one returning atomic on its image's ticket, ~11 ns apart on one address
     // 256 blocks per image at most (a block ends with one returning atomic on its image's ticket, ~11 ns apart on one address), 128
-    // with a batch behind them. Measured with rocprofv3 (profiles/r03_minmax_shapes.txt): 8 x 2048^2 21.3 us, one 2048^2 image
-    // 5.8 - 7.3 us, one 8192^2 image 39 - 40 us whatever the shape (256 ... 1024 threads, 4 / 8 loads per lane, 64 ... 2048 blocks per image,
-    // chunks contiguous or a grid-width apart): the launch follows the previous step's gradation apply (268 MB of plain stores
-    // at 8 x 2048^2) and reads while that write backlog drains.
+    // with a batch behind them. Measured with rocprofv3 (profiles/r03_minmax_shapes.txt, r04_minmax.txt): 8 x 2048^2 21 - 22 us, one
+    // 2048^2 image 5.8 - 7.3 us, one 8192^2 image 39 - 40 us whatever the shape (256 ... 1024 threads, 1 ... 8 loads per lane, 64 ... 2048
+    // blocks per image, chunks contiguous or a grid-width apart, images skewed against each other). Round 3 blamed the previous step's
+    // gradation apply (268 MB of stores still draining); round 4 refuted that: first in its stream on a drained, idle device the launch
+    // takes 23.5 us, and its streaming loop alone (no clears, no ticket tail, the grid of a plain copy kernel) 19.5 us.
     const size_t per_block = (size_t)kMinMaxThreads * kMinMaxLoads;
     size_t blocks = (count / 8 + per_block - 1) / per_block;
     const size_t maxb = batch >= 4 ? 128 : 256;

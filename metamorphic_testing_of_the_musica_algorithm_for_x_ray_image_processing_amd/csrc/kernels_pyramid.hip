@@ -145,7 +145,32 @@ constexpr int kDmaRows = 4;                           // output rows per workgro
 constexpr int kDmaInRows = 2 * kDmaRows + 3;          // input rows of a tile
 constexpr int kDmaPieces = 2 * kDmaInRows;            // 1 KiB pieces (half rows)
 constexpr int kDmaPiecesPerWave = (kDmaPieces + kWavesPerBlock - 1) / kWavesPerBlock;
-static_assert(kDmaRows == kWavesPerBlock && kDmaInRows * 3 <= 64, "tile shape");
+constexpr int kDmaHaloLanes = 24;                     // lanes of the halo DMA (2 per input row, rounded up to a multiple of 8)
+static_assert(kDmaRows == kWavesPerBlock && kDmaInRows * 2 <= kDmaHaloLanes, "tile shape");
+
+// Workgroup -> tile for the metric kernel when the strip count is a power of two of at least 2 and the tile rows divide: XCD k (the
+// workgroups with linear id % 8 == k) owns a REGION of the image, two strips wide (region_width) and 1 / v of the tile rows tall where
+// (strips / 2) v = 8, and walks it row of tiles by row of tiles,
+// strip by strip: the tiles left / right and above / below a tile are on the same XCD and dispatched back to back, so the halo
+// columns (the neighbouring strip's lines) and the shared halo rows are found in that XCD's L2 — with one strip per XCD (the plain
+// mapping at 8 strips) every halo column was another XCD's line and came from the fabric a second time.
+// strip PAIRS (quads from 32 strips): 4096^2 = 4 pairs across x 2 halves down, 8192^2 = 8 pairs x the full height, 2048^2 = 2 pairs x 4 quarters.
+// Measured at 4096^2 / 8192^2 (us per launch from HBM, fetch + write traffic): pairs 14.62 / 52.5, 87.2 MB; regions of half the strips x
+// a quarter of the rows 15.0 / 53.7, 85.2 MB (less fetch, slower); one strip per XCD (round 3) 14.86 / 52.0, 91.3 MB.
+__host__ __device__ __forceinline__ unsigned region_width(unsigned strips) { return strips >= 32u ? strips >> 3 : 2u; }
+__device__ __forceinline__ Tile xcd_region_tile() {
+    const unsigned gx = gridDim.x, gy = gridDim.y;           // strips, tile rows
+    const unsigned lin = blockIdx.x + gx * blockIdx.y;
+    const unsigned xcd = lin & 7u, j = lin >> 3;
+    const unsigned w = region_width(gx);                     // region width in strips
+    const unsigned across = gx / w, v = 8u / across;          // regions across x regions down = 8
+    const unsigned rh = gy / v;                               // tile rows per region
+    const unsigned rx = xcd % across, ry = xcd / across;
+    Tile t;
+    t.strip = (int)(rx * w + j % w);
+    t.segblock = (int)(ry * rh + j / w);
+    return t;
+}
 
 // M0 = LDS byte address the wave-instruction writes to (wave-uniform); lane l lands at M0 + 16 l (dwordx4) / M0 + 4 l (dword).
 // An asm load is invisible to hipcc's s_waitcnt bookkeeping: the kernel waits with its own vmcnt(0) below.
@@ -171,10 +196,10 @@ template <int TAG>
 __global__ __launch_bounds__(kBlockThreads) void k_reduce_dma(const float* __restrict__ in, float* __restrict__ out,
                                                               int S, int pitch, size_t in_plane, int So, int opitch,
                                                               size_t out_plane, int swz) {
-    __shared__ __attribute__((aligned(16))) float tile_s[kDmaInRows * kStripCols + 64];
+    __shared__ __attribute__((aligned(16))) float tile_s[kDmaInRows * kStripCols + kDmaHaloLanes * 4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const Tile tile = xcd_tile(swz);
+    const Tile tile = swz == 2 ? xcd_region_tile() : xcd_tile(swz);
     const int yo0 = tile.segblock * kDmaRows;
     const Buf ib = make_buf(in + (size_t)blockIdx.z * in_plane, in_plane * 4);
     const Buf ob = make_buf(out + (size_t)blockIdx.z * out_plane, out_plane * 4);
@@ -184,13 +209,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_dma(const float* __res
     const uint32_t rb = (uint32_t)pitch * 4u, orb = (uint32_t)opitch * 4u;
     const uint32_t lds0 = (uint32_t)(uintptr_t)tile_s;   // LDS byte address of the tile (low half of the flat address)
     // local row k of the tile = input row mirror(2 * yo0 - 2 + k) (img_smooth.comp:10-16), kept inside the image
-    // halo columns of every row, one dword each: entry 3 k + j, j = 0: c0-2, 1: c0-1, 2: c0+512 (wavefront 0 only)
-    if (wave == 0) {
-        const int k = lane / 3, j = lane - 3 * k;
+    // halo columns of every row as two aligned 16-byte pieces — columns c0-4 .. c0-1 and c0+512 .. c0+515 — by ONE dwordx4 DMA of
+    // 2 x 11 lanes (wavefront 0; entry 2 k + side, 4 floats each). Until round 4 a dword DMA gathered the three columns a row needs
+    // one by one: 33 requests per tile, each a fabric request of its own on a line of the neighbouring strip (+9 % of fetch, PMC);
+    // 22 now, and with the region mapping below the neighbour's line is usually in this XCD's L2 already.
+    if (wave == 0 && lane < kDmaHaloLanes) {
+        const int k = lane >> 1, side = lane & 1;
         const int y = min(max(mirror_idx(2 * yo0 - 2 + min(k, kDmaInRows - 1), hi), 0), hi);
-        const int col = j == 0 ? c0 - 2 : j == 1 ? c0 - 1 : c0 + kStripCols;
+        const int col = side ? c0 + kStripCols : c0 - 4;
         const bool ok = k < kDmaInRows && col >= 0 && col < S;
-        dma4(ib, ok ? (uint32_t)y * rb + (uint32_t)col * 4u : kOob, lds0 + (uint32_t)(kDmaInRows * kStripCols) * 4u);
+        dma16(ib, ok ? (uint32_t)y * rb + (uint32_t)col * 4u : kOob, lds0 + (uint32_t)(kDmaInRows * kStripCols) * 4u);
     }
     const uint32_t lane_off = (uint32_t)(c0 + lane * 4) * 4u;   // a piece = 256 columns, 4 per lane
 #pragma unroll
@@ -216,7 +244,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_reduce_dma(const float* __res
         const float4 a = *reinterpret_cast<const float4*>(tile_s + k * kStripCols + lane * 8);
         const float4 b = *reinterpret_cast<const float4*>(tile_s + k * kStripCols + lane * 8 + 4);
         w[r].v[0] = a.x; w[r].v[1] = a.y; w[r].v[2] = a.z; w[r].v[3] = a.w; w[r].v[4] = b.x; w[r].v[5] = b.y; w[r].v[6] = b.z; w[r].v[7] = b.w;
-        w[r].hl0 = hal[3 * k]; w[r].hl1 = hal[3 * k + 1]; w[r].hr = hal[3 * k + 2];
+        w[r].hl0 = hal[8 * k + 2]; w[r].hl1 = hal[8 * k + 3]; w[r].hr = hal[8 * k + 4];   // columns c0-2, c0-1 | c0+512
     }
     const int yo = yo0 + wave;
     if (yo < So) reduce_row<2>(w[0], w[1], w[2], w[3], w[4], g, ob, (uint32_t)yo * orb);   // wave-uniform
@@ -1052,6 +1080,10 @@ int xcd_swizzle_on() {
     return on;
 }
 
+static int region_map_on() {   // MUSICA_XCD_REGIONS=0: the round-3 tile mapping of the metric kernel
+    static const int on = getenv("MUSICA_XCD_REGIONS") ? atoi(getenv("MUSICA_XCD_REGIONS")) : 1;
+    return on;
+}
 static inline dim3 stream_grid(int S, int rows, int rows_per_wave, int batch) {
     const int strips = (S + kStripCols - 1) / kStripCols;
     const int segs = (rows + rows_per_wave - 1) / rows_per_wave;
@@ -1068,8 +1100,15 @@ void launch_reduce(hipStream_t st, const float* in, const LevelDesc& li, float* 
         const int strips = (li.S + kStripCols - 1) / kStripCols;
         const dim3 grid(strips, (lo.S + kDmaRows - 1) / kDmaRows, batch);
         // 8 k strips: workgroup id % 8 == strip % 8 already gives every strip one XCD, tile above tile in dispatch order; otherwise
-        // the XCD-aware mapping does (2048^2: 6.0 -> 5.05 us; it costs 1.5 us at 4096^2 where the plain mapping has that property)
-        const int swz = (strips % 8) != 0 ? xcd_swizzle_on() : 0;
+        // the XCD-aware mapping does (2048^2: 6.0 -> 5.05 us; it costs 1.5 us at 4096^2 where the plain mapping has that property).
+        // Round 4: where the geometry allows, 2-D regions per XCD (xcd_region_tile): horizontal neighbours share an L2 as well.
+        int swz = (strips % 8) != 0 ? xcd_swizzle_on() : 0;
+        {
+            const unsigned gx = (unsigned)strips, gy = grid.y;
+            const bool pow2 = gx >= 2 && (gx & (gx - 1)) == 0 && gx <= 32;
+            const unsigned w = region_width(gx), across = pow2 ? gx / w : 1u, v = pow2 ? 8u / across : 1u;
+            if (pow2 && across * v == 8u && gy % v == 0 && xcd_swizzle_on() && region_map_on()) swz = 2;
+        }
         auto* kern = tag == 0 ? k_reduce_dma<0> : tag == 1 ? k_reduce_dma<1> : tag == 2 ? k_reduce_dma<2> : tag == 4 ? k_reduce_dma<4> : k_reduce_dma<5>;
         hipLaunchKernelGGL(kern, grid, dim3(kBlockThreads), 0, st, in, out, li.S, li.pitch, li.plane, lo.S, lo.pitch, lo.plane, swz);
     } else {
