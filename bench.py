@@ -464,6 +464,31 @@ def main():
         if not proc.execute_stream([pinned[j & 1] for j in range(reps)]):
             raise SystemExit("musica_execute_stream failed: " + mp.last_error())
         e2e_stream = reps * batch * n * n / 1e6 / (time.perf_counter() - te0)
+        # BASELINE configs[3] as it is stated — ONE pass over a host-resident shard: pinned host pixels -> H2D -> one step -> stats rows,
+        # wall time of musica_execute (image k's chain starts when image k has landed) + the stats read-back; median of 7 passes
+        one_pass = []
+        rows_dev = torch.zeros((batch, mb.STATS_WORDS), dtype=torch.int32, device="cuda:%d" % local_rank)
+        def pass_once():
+            tp0 = time.perf_counter()
+            if not proc.execute(pinned[0]):
+                raise SystemExit("musica_execute failed: " + mp.last_error())
+            proc.stats_device(rows_dev.data_ptr(), 0, 1)
+            proc.sync()
+            rows_dev.cpu()
+            return time.perf_counter() - tp0
+        for _ in range(8):
+            one_pass.append(pass_once())
+        one_pass = sorted(one_pass[1:])
+        one_pass_ms = one_pass[len(one_pass) // 2] * 1e3
+        whole = None
+        if batch > 1:   # the same pass with the batch copied and computed as a whole (MUSICA_HOST_LANES=0): what the lanes buy
+            os.environ["MUSICA_HOST_LANES"] = "0"
+            tw = []
+            for _ in range(6):
+                tw.append(pass_once())
+            del os.environ["MUSICA_HOST_LANES"]
+            tw = sorted(tw[1:])
+            whole = tw[len(tw) // 2] * 1e3
         for b in pinned:
             proc.host_free(b)
         # BASELINE configs[1] beside the batched workload: ONE image of the same size per execute, as the reference's
@@ -596,6 +621,11 @@ def main():
             "one_context": {"ms_per_step": round(one_ctx_ms, 4), "value": round(batch * n * n / 1e6 / (one_ctx_ms * 1e-3), 1), "unit": "MP/s per GPU",
                             "what": "the same %d steps on one context alone (%s), each step behind the previous one (rank 0)" % (args.steps, proc.dispatch_text())},
             "e2e_host_MPps": round(e2e, 1),
+            "job_one_pass": {"what": "BASELINE configs[3] per GPU as stated: ONE pass over a host-resident shard — %d x %dx%d pinned host pixels -> H2D -> one step -> "
+                                     "stats rows (musica_execute: image k's chain starts when image k has landed; median of 7 passes; PCIe-inclusive, never `value`)" % (batch, n, n),
+                             "wall_ms": round(one_pass_ms, 4), "value": round(batch * n * n / 1e6 / (one_pass_ms * 1e-3), 1), "unit": "MP/s",
+                             "pcie_bound_ms": round(batch * n * n * 2 / 63e9 * 1e3, 4), "fraction_of_pcie_bound": round(batch * n * n * 2 / 63e9 * 1e3 / one_pass_ms, 3),
+                             "whole_batch_wall_ms": None if whole is None else round(whole, 4)},
             "e2e_host_overlapped": {"value": round(e2e_stream, 1), "unit": "MP/s", "what": "musica_execute_stream over %d batches in pinned host memory: H2D of batch j+1 under the kernels of batch j (PCIe-inclusive; never `value`)" % reps,
                                     "pcie_bound_MPps": round(63e9 / 2 / 1e6, 1), "fraction_of_device_rate": round(e2e_stream / (mpix / elapsed), 3)},
             "single_image": single,

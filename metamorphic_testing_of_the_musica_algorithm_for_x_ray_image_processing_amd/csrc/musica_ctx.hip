@@ -138,7 +138,18 @@ struct musica_ctx {
     size_t spans_used;
     double prof_total_us[MUSICA_KERNEL_COUNT];
     uint64_t prof_count[MUSICA_KERNEL_COUNT];
+    bool needs_reset;        // a step failed (launch / sync error): the self-resetting tickets of k_minmax_u16 and k_grad_recount_curve may hold a
+                             // partial count, which would leave every later launch without a last-ticket block — zeroed before the next step
     std::vector<void*> allocations;
+    // Image lanes (musica_execute of a context with a batch, from page-locked host memory): shallow copies of the context for one or
+    // two images each — device pointers moved to those images — whose one-stream script is enqueued behind the host-to-device copy of
+    // just those images. Every stage of the path is per image, so nothing changes in the results; the first images' kernels run under
+    // the remaining copies. Created on first use.
+    std::vector<musica_ctx*> lanes;
+    hipStream_t lane_stream[3];
+    hipStream_t lane_copy[2];        // the images' copies ([1]: unused; two alternating copy streams made every copy twice as long)
+    hipEvent_t lane_done[3], lane_start;
+    std::vector<hipEvent_t> img_copied;   // one per image
 };
 
 static int env_int(const char* name, int dflt) {
@@ -237,6 +248,19 @@ void musica_destroy(musica_ctx* c) {
     if (!c) return;
     hipSetDevice(c->p.device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    for (int k = 0; k < 3; k++) if (c->lane_stream[k]) hipStreamSynchronize(c->lane_stream[k]);
+    for (musica_ctx* v : c->lanes) {
+        for (auto& sp : v->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
+        for (int k = 0; k < kGraphSlots; k++) if (v->graph_exec[k]) hipGraphExecDestroy(v->graph_exec[k]);
+        delete v;
+    }
+    for (int k = 0; k < 3; k++) {
+        if (c->lane_stream[k]) { hipStreamSynchronize(c->lane_stream[k]); hipStreamDestroy(c->lane_stream[k]); }
+        if (c->lane_done[k]) hipEventDestroy(c->lane_done[k]);
+    }
+    if (c->lane_start) hipEventDestroy(c->lane_start);
+    for (int k = 0; k < 2; k++) if (c->lane_copy[k]) { hipStreamSynchronize(c->lane_copy[k]); hipStreamDestroy(c->lane_copy[k]); }
+    for (hipEvent_t e : c->img_copied) hipEventDestroy(e);
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     for (int k = 0; k < 2; k++) {
         if (c->ev_copied[k]) hipEventDestroy(c->ev_copied[k]);
@@ -294,7 +318,9 @@ static musica_ctx* create_impl(const musica_params* params) {
     c->generic = (params->flags & MUSICA_FLAG_GENERIC_KERNELS) != 0 || c->ref_order;   // the literal order lives in the one-thread-per-texel kernels
     c->tuning = false;
     c->stream = nullptr; c->side = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr; c->profiling = 0; c->spans_used = 0; c->cur_input = nullptr;
-    c->d_out8 = nullptr; c->h_out8 = nullptr;
+    c->d_out8 = nullptr; c->h_out8 = nullptr; c->needs_reset = false;
+    for (int k = 0; k < 3; k++) { c->lane_stream[k] = nullptr; c->lane_done[k] = nullptr; }
+    c->lane_start = nullptr; c->lane_copy[0] = c->lane_copy[1] = nullptr;
     c->d_input2 = nullptr; c->copy_stream = nullptr; c->ev_copied[0] = c->ev_copied[1] = c->ev_consumed[0] = c->ev_consumed[1] = nullptr;
     memset(c->prof_total_us, 0, sizeof(c->prof_total_us));
     memset(c->prof_count, 0, sizeof(c->prof_count));
@@ -761,7 +787,22 @@ static int capture_graph(musica_ctx* c) {
     return k;
 }
 
+static void reset_tickets_if_needed(musica_ctx* c) {
+    if (!c->needs_reset) return;
+    hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
+    hipMemsetAsync(c->d_mm_ticket, 0, (size_t)c->B * kMinMaxStride * sizeof(uint32_t), c->stream);
+    hipMemsetAsync(c->d_gr_ticket, 0, (size_t)c->B * kGradTicketStride * sizeof(uint32_t), c->stream);
+    c->needs_reset = false;
+}
+static int enqueue_all_impl(musica_ctx* c);
 static int enqueue_all(musica_ctx* c) {
+    reset_tickets_if_needed(c);
+    const int ok = enqueue_all_impl(c);
+    if (!ok) c->needs_reset = true;
+    return ok;
+}
+static int enqueue_all_impl(musica_ctx* c) {
     if (!c->tuning && c->use_graph && c->profiling == 0) {
         int k = -1;
         for (int j = 0; j < kGraphSlots; j++)
@@ -879,9 +920,153 @@ static int download_small(musica_ctx* c, const T* d_src, T* dst, size_t count) {
 
 extern "C" {
 
+// ---- image lanes (see musica_ctx::lanes) ----------------------------------------------------------------------------------
+constexpr int kLaneStreams = 1;   // one: a one-image chain (0.14 - 0.19 ms) is as long as an image's copy, so chains on several streams would barely
+                                  // overlap, and which hardware queue a further stream lands on (4 queues, round-robin over every stream of the
+                                  // process) decided whether three lanes were faster or slower than none
+// Shallow copy of the context restricted to image i0: same buffers, every per-image pointer moved to that image, batch 1, one stream,
+// its script replayed as a graph of its own.
+static musica_ctx* make_lane(const musica_ctx* c, int i0, int nb) {
+    musica_ctx* v = new musica_ctx(*c);
+    v->allocations.clear();   // the parent owns the memory, the streams and the events
+    v->spans.clear();
+    v->spans_used = 0;
+    v->lanes.clear();
+    v->img_copied.clear();
+    v->side = nullptr; v->ev_fork = nullptr; v->ev_join = nullptr; v->copy_stream = nullptr;
+    for (int k = 0; k < kGraphSlots; k++) { v->graph_exec[k] = nullptr; v->graph_input[k] = nullptr; v->graph_used[k] = 0; }
+    v->use_graph = !(c->p.flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", 1) != 0;   // one graph per lane and input buffer: the host
+                                                                                             // enqueues 8 replays per batch instead of ~136 launches
+    v->dag = 0;
+    v->profiling = 0;
+    v->B = nb;
+    v->p.batch = (uint32_t)nb;
+    const size_t o = (size_t)i0, NN = (size_t)c->N * c->N;
+    v->d_input += o * NN;
+    v->cur_input = v->d_input;
+    v->d_minmax += o * kMinMaxStride;
+    v->d_mm_slots += o * kMinMaxSlots;
+    v->d_mm_ticket += o * kMinMaxStride;
+    v->d_gr_ticket += o * kGradTicketStride;
+    v->d_norm += o * c->lv[0].plane;
+    for (int i = 0; i < c->L; i++) {
+        v->d_down[i] += o * c->lv[i + 1].plane;
+        v->d_band[i] += o * c->lv[i].plane;
+        v->d_recon[i] += o * c->lv[i].plane;
+        if (i <= MUSICA_CNR_LEVEL) v->d_sdev[i] += o * c->lv[i].plane;
+    }
+    v->d_noise_hist += o * 4 * MUSICA_NOISE_BINS;
+    v->d_noise_max += o * c->L;
+    v->d_curves += o * c->L;
+    v->d_luts += o * MUSICA_COARSER_LEVELS_START;
+    v->d_cnr += o * c->lv[MUSICA_CNR_LEVEL].plane;
+    v->d_grad_hist += o * MUSICA_GRAD_BINS;
+    v->d_grad_hist_b += o * MUSICA_GRAD_BINS;
+    v->d_gzero += o;
+    v->d_thr090 += o;
+    v->d_stats_partial += o * kStatsMaxBlocks;
+    if (v->d_le090) v->d_le090 += o * (size_t)c->lv[1].S * (c->lv[0].S / 8);
+    v->d_grad_max += o;
+    v->d_gcurve += o;
+    v->d_graded += o * c->lv[0].plane;
+    v->d_scratch += o * c->lv[0].plane;
+    v->d_stats += o;
+    if (c->d_clahe_hist) {
+        const size_t tb = (size_t)MUSICA_CLAHE_TILES * MUSICA_CLAHE_TILES * MUSICA_CLAHE_BINS;
+        v->d_clahe_hist += o * tb;
+        v->d_clahe_pts += o * tb;
+        v->d_clahe_graded += o * c->lv[0].plane;
+    }
+    for (int i = 0; i < c->L; i++) {   // launch geometry of a one-image step (results never depend on it)
+        v->rows_expand[i] = pick_rows(c->expand_rows, 1, c->lv[i].S, c->lv[i + 1].S, nb);
+        if (i <= MUSICA_CNR_LEVEL) v->rows_sdev[i] = sdev_rows_default(c, i, nb);
+        v->rows_rb[i] = pick_rows(16, 1, c->lv[i].S, c->lv[i + 1].S, nb);
+    }
+    return v;
+}
+// Only for page-locked host memory (musica_host_alloc, hipHostMalloc, hipHostRegister): a copy from pageable memory is staged by the
+// runtime and blocks the host meanwhile, so eight of them in a row are slower than one (8 x 2048^2: 2.5 ms against 1.7 ms per batch).
+static bool lanes_wanted(const musica_ctx* c, const void* host_pixels) {
+    if (!(c->B > 1 && c->profiling == 0 && !c->tuning && env_int("MUSICA_HOST_LANES", 1) != 0)) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, host_pixels) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+static bool ensure_lanes(musica_ctx* c) {
+    if (!c->lanes.empty()) return true;
+    bool ok = true;
+    for (int k = 0; k < 2 && ok; k++)
+        if (!c->lane_copy[k]) ok = hipStreamCreateWithFlags(&c->lane_copy[k], hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < kLaneStreams && ok; k++) {
+        if (!c->lane_stream[k]) ok = ok && hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking) == hipSuccess;
+        if (!c->lane_done[k]) ok = ok && hipEventCreateWithFlags(&c->lane_done[k], hipEventDisableTiming) == hipSuccess;
+    }
+    if (ok && !c->lane_start) ok = hipEventCreateWithFlags(&c->lane_start, hipEventDisableTiming) == hipSuccess;
+    while (ok && (int)c->img_copied.size() < c->B) {
+        hipEvent_t e = nullptr;
+        ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (ok) c->img_copied.push_back(e);
+    }
+    if (!ok) return false;
+    // images per lane: the chain of a lane should be shorter than its copy, or the lanes queue up behind each other instead of behind the
+    // link — one 2048^2 image: 0.17 - 0.19 ms of kernels against 0.155 ms of copy; two: 0.18 ms against 0.31 ms
+    const int per = c->B >= 4 ? 2 : 1;
+    for (int k = 0; k < c->B; k += per) {   // last: c->lanes non-empty means everything above exists
+        musica_ctx* v = make_lane(c, k, c->B - k < per ? c->B - k : per);
+        v->stream = c->lane_stream[(k / per) % kLaneStreams];
+        v->cur = v->stream;
+        c->lanes.push_back(v);
+    }
+    return true;
+}
+// One batch from host memory into `d_dst` (c->d_input or the streaming path's second buffer), image by image: copy k on the copy
+// stream, image k's one-stream script behind it on lane stream k % 3; the context's own stream continues when every lane has finished.
+// `after`: an event the copies must wait for (the buffer's previous reader), or null.
+static int enqueue_images_from_host(musica_ctx* c, uint16_t* d_dst, const uint16_t* pixels, bool copies_wait = true) {
+    const size_t NN = (size_t)c->N * c->N;
+    reset_tickets_if_needed(c);
+    // whatever the context's stream still runs (the previous step: it reads and writes the planes the lanes are about to overwrite) comes
+    // first; the copies too unless the caller knows `d_dst` is free (the streaming path's double buffer)
+    hipEventRecord(c->lane_start, c->stream);
+    if (copies_wait) { hipStreamWaitEvent(c->lane_copy[0], c->lane_start, 0); hipStreamWaitEvent(c->lane_copy[1], c->lane_start, 0); }
+    for (int k = 0; k < kLaneStreams; k++) hipStreamWaitEvent(c->lane_stream[k], c->lane_start, 0);
+    // every copy first (the host takes ~100 us to enqueue one lane's replay: with copy k + 1 enqueued behind lane k the copy engine
+    // idled between the images — 1.68 ms for the eight copies of 8 x 2048^2 instead of 1.24), then the lanes
+    int first = 0;
+    for (size_t l = 0; l < c->lanes.size(); l++) {
+        const int nb = c->lanes[l]->B;
+        if (hipMemcpyAsync(d_dst + (size_t)first * NN, pixels + (size_t)first * NN, (size_t)nb * NN * sizeof(uint16_t), hipMemcpyHostToDevice, c->lane_copy[0]) != hipSuccess)
+            return fail("host-to-device copy of images %d.. failed: %s", first, hipGetErrorString(hipGetLastError()));
+        hipEventRecord(c->img_copied[l], c->lane_copy[0]);
+        first += nb;
+    }
+    first = 0;
+    for (size_t l = 0; l < c->lanes.size(); l++) {
+        musica_ctx* v = c->lanes[l];
+        const int k = first;
+        first += v->B;
+        hipStreamWaitEvent(v->stream, c->img_copied[l], 0);
+        v->cur_input = d_dst + (size_t)k * NN;
+        v->cur = v->stream;
+        if (!enqueue_all_impl(v)) { c->needs_reset = true; return 0; }
+    }
+    for (int k = 0; k < kLaneStreams; k++) {
+        hipEventRecord(c->lane_done[k], c->lane_stream[k]);
+        hipStreamWaitEvent(c->stream, c->lane_done[k], 0);
+    }
+    c->cur_input = d_dst;
+    c->norm_valid = c->lanes[0]->norm_valid;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { c->needs_reset = true; return fail("per-image dispatch failed: %s", hipGetErrorString(e)); }
+    return 1;
+}
+
 int musica_sync(musica_ctx* c) {
     CHECK_CTX(c);
-    HIP_OK(hipStreamSynchronize(c->stream));
+    {
+        const hipError_t e_ = hipStreamSynchronize(c->stream);
+        if (e_ != hipSuccess) { c->needs_reset = true; return fail("hipStreamSynchronize failed: %s", hipGetErrorString(e_)); }
+    }
     if (c->profiling) collect_spans(c);
     return 1;
 }
@@ -905,12 +1090,19 @@ int musica_execute_device(musica_ctx* c, const uint16_t* d_pixels) {
 }
 
 int musica_execute(musica_ctx* c, const uint16_t* pixels) {
+    ABI_TRY
     CHECK_CTX(c);
     if (!pixels) return fail("musica_execute: pixels is NULL");
+    if (lanes_wanted(c, pixels)) {   // a batch in pinned memory: image k's chain starts when image k has landed (the copy of a batch takes 2 - 3 x its kernels)
+        if (!ensure_lanes(c)) return fail("musica_execute: stream / event creation for the image lanes failed");
+        if (!enqueue_images_from_host(c, c->d_input, pixels, true)) return 0;
+        return musica_sync(c);
+    }
     HIP_OK(hipMemcpyAsync(c->d_input, pixels, (size_t)c->B * c->N * c->N * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));  // vk_state.cpp:313-342
     c->cur_input = c->d_input;
     if (!enqueue_all(c)) return 0;
     return musica_sync(c);  // vkWaitForFences, src/vk_processing.cpp:2535-2536
+    ABI_CATCH("musica_execute")
 }
 
 // The reference uploads every image through a freshly allocated staging buffer and three queue-idle waits before a single
@@ -919,18 +1111,22 @@ int musica_execute(musica_ctx* c, const uint16_t* pixels) {
 // batch j and the host only blocks at the very end. Input in pinned memory (musica_host_alloc) moves at the PCIe rate;
 // pageable memory works too (the runtime stages it, slower and partly synchronous).
 int musica_execute_stream(musica_ctx* c, const uint16_t* const* pixels, uint32_t count, musica_stats* stats) {
+    ABI_TRY
     CHECK_CTX(c);
     if (!pixels) return fail("musica_execute_stream: pixels is NULL");
     const size_t bytes = (size_t)c->B * c->N * c->N * sizeof(uint16_t);
-    if (!c->d_input2) {
-        if (!dalloc(c, &c->d_input2, (size_t)c->B * c->N * c->N)) return fail("musica_execute_stream: device allocation failed");
-        HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->ev_consumed[1]) {   // keyed on the LAST resource of the block: a call that failed half-way is retried, never half-initialised
+        if (!c->d_input2 && !dalloc(c, &c->d_input2, (size_t)c->B * c->N * c->N)) return fail("musica_execute_stream: device allocation failed");
+        if (!c->copy_stream) HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) {
-            HIP_OK(hipEventCreateWithFlags(&c->ev_copied[k], hipEventDisableTiming));
-            HIP_OK(hipEventCreateWithFlags(&c->ev_consumed[k], hipEventDisableTiming));
+            if (!c->ev_copied[k]) HIP_OK(hipEventCreateWithFlags(&c->ev_copied[k], hipEventDisableTiming));
+            if (!c->ev_consumed[k]) HIP_OK(hipEventCreateWithFlags(&c->ev_consumed[k], hipEventDisableTiming));
         }
     }
     if (count == 0) return 1;
+    // (Whole batches: the copy of batch j + 1 under the kernels of batch j already moves the pixels at the rate the link delivers — 53 - 54 GB/s
+    // here. The image lanes of musica_execute were measured in this loop too: 20 - 22 GP/s against 26.5, the host needs ~0.8 ms per batch
+    // to enqueue eight replays and the next batch's copies wait behind that.)
     musica_stats* d_rows = nullptr;
     musica_stats* h_rows = nullptr;
     struct RowsGuard {   // the two scratch buffers go away on every exit path
@@ -969,6 +1165,7 @@ int musica_execute_stream(musica_ctx* c, const uint16_t* const* pixels, uint32_t
     if (e != hipSuccess) return fail("musica_execute_stream: %s", hipGetErrorString(e));
     if (c->profiling) collect_spans(c);
     return ok;
+    ABI_CATCH("musica_execute_stream")
 }
 
 void* musica_host_alloc(musica_ctx* c, size_t bytes) {
