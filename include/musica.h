@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MUSICA_ABI_VERSION 2
+#define MUSICA_ABI_VERSION 3
 
 /* Hard-coded constants of the reference. */
 #define MUSICA_MAX_LEVELS 16          /* reference: 12 + 1 clear buffers, vk_processing.h:67 */
@@ -120,6 +120,24 @@ typedef struct musica_params {
     uint32_t flags;      /* MUSICA_FLAG_* */
 } musica_params;
 
+/* The reference's compile-time configuration of the contrast and noise-reduction parameter formulas as runtime values (ABI version 3).
+ * Replaces: the private constants of include/vk_processing.h:39-49 (nrHighCnr, nrMaxHighFactor, nrLowCnr, nrMinLowFactor,
+ * highContrastMaxReduction, lowContrastMaxEnhancment) and the two #defines of include/vk_processing.h:16-17
+ * (LINEAR_LOW_CONTRAST_LEVELS_REDUCTION, LINEAR_HIGH_CONTRAST_LEVELS_REDUCTION) that select the linear instead of the power form of
+ * src/vk_processing.cpp:262-293. musica_tunables_default() fills in the reference's values (both #defines are commented out there).
+ * coarserLevelsStart = 3 and cnrLevel = 3 (vk_processing.h:28-29) stay compile-time constants here as well
+ * (MUSICA_COARSER_LEVELS_START, MUSICA_CNR_LEVEL): they decide which images and launches exist, not a formula. */
+typedef struct musica_tunables {
+    float nr_high_cnr;                  /* nrHighCnr = 9.0f */
+    float nr_max_high_factor;           /* nrMaxHighFactor = 1.2f */
+    float nr_low_cnr;                   /* nrLowCnr = 3.0f */
+    float nr_min_low_factor;            /* nrMinLowFactor = 0.6f */
+    float high_contrast_max_reduction;  /* highContrastMaxReduction = 0.2f */
+    float low_contrast_max_enhancement; /* lowContrastMaxEnhancment = 3.0f */
+    uint32_t linear_low_contrast;       /* != 0: #define LINEAR_LOW_CONTRAST_LEVELS_REDUCTION  (src/vk_processing.cpp:282-287) */
+    uint32_t linear_high_contrast;      /* != 0: #define LINEAR_HIGH_CONTRAST_LEVELS_REDUCTION (src/vk_processing.cpp:262-268) */
+} musica_tunables;
+
 typedef struct musica_ctx musica_ctx;
 
 /* Image kinds addressable by musica_get_image / musica_debug_set_image.
@@ -161,6 +179,12 @@ typedef enum musica_stage {
  * std::vector<VkImageView>*) (vk_processing.h:281-288, src/vk_processing.cpp:1984-2020).
  * Allocates every device buffer once; returns NULL on failure. */
 musica_ctx* musica_create(const musica_params* params);
+/* The same with the parameter formulas' constants given by the caller (NULL: the reference's). Values the formulas cannot use
+ * (nr_high_cnr == nr_low_cnr, non-finite numbers) are refused. */
+musica_ctx* musica_create_ex(const musica_params* params, const musica_tunables* tunables);
+void musica_tunables_default(musica_tunables* out);
+/* the tunables a context was created with */
+int musica_get_tunables(const musica_ctx* ctx, musica_tunables* out);
 
 /* Replaces: bool VulkanProcessing::cleanup() (src/vk_processing.cpp:2647-2651). Frees everything. */
 void musica_destroy(musica_ctx* ctx);
@@ -281,6 +305,7 @@ int musica_render_grad_hist(musica_ctx* ctx, uint32_t image_index, uint8_t* rgba
 typedef struct musica_pipeline musica_pipeline;
 #define MUSICA_PIPELINE_QUEUES 4
 musica_pipeline* musica_pipeline_create(const musica_params* params, uint32_t depth);
+musica_pipeline* musica_pipeline_create_ex(const musica_params* params, uint32_t depth, const musica_tunables* tunables);   /* NULL: the reference's constants */
 void musica_pipeline_destroy(musica_pipeline* p);
 uint32_t musica_pipeline_depth(const musica_pipeline* p);
 /* k-th context: before prime() k < max(depth, MUSICA_PIPELINE_QUEUES) (depth 1: one), afterwards k < depth, in step order. */

@@ -59,6 +59,7 @@ constexpr int kGraphSlots = 4;
 
 struct musica_ctx {
     musica_params p;
+    musica_tunables tun;     // the constants of the host parameter formulas (musica_create_ex; default: the reference's)
     int N, L, B;
     bool generic;
     int ref_order;           // MUSICA_FLAG_REFERENCE_ORDER: generic kernels in the shaders' literal 25-tap accumulation order
@@ -171,25 +172,32 @@ static bool dalloc(musica_ctx* c, T** out, size_t count) {
     return true;
 }
 
-// highContrastFactor / lowContrastFactor per level: src/vk_processing.cpp:259-293 (non-LINEAR branches).
-static musica_contrast_params host_contrast_params(uint32_t i, uint32_t levels) {
+// highContrastFactor / lowContrastFactor per level: src/vk_processing.cpp:259-293, both forms of each (the reference picks one per
+// #define LINEAR_*_CONTRAST_LEVELS_REDUCTION, include/vk_processing.h:16-17; musica_tunables carries the choice).
+static musica_contrast_params host_contrast_params(uint32_t i, uint32_t levels, const musica_tunables& t) {
     const uint32_t coarserLevelsStart = MUSICA_COARSER_LEVELS_START;
-    const float highContrastMaxReduction = 0.2f, lowContrastMaxEnhancment = 3.0f;  // vk_processing.h:48-49
+    const float highContrastMaxReduction = t.high_contrast_max_reduction, lowContrastMaxEnhancment = t.low_contrast_max_enhancement;  // vk_processing.h:48-49
     musica_contrast_params cp;
     const uint32_t coarserLevelsCount = levels - coarserLevelsStart;
     if (i < coarserLevelsStart) cp.highContrastFactor = 1.0f;
-    else {
+    else if (t.linear_high_contrast) {
+        // :264-268 — divides by (pyramidLevels - coarserLevelsStart - 1): 0 / 0 at L = 4, taken as "no reduction" like the power form's exponent 0
+        cp.highContrastFactor = coarserLevelsCount > 1
+            ? 1.0f - (float)(i - coarserLevelsStart) * (1.0f - highContrastMaxReduction) / (float)(levels - coarserLevelsStart - 1) : 1.0f;
+    } else {
         // the reference divides by (coarserLevelsCount - 1): 0/0 at L = 4 — taken as exponent 0 there
         const float e = coarserLevelsCount > 1 ? (float)(i - coarserLevelsStart) / (float)(coarserLevelsCount - 1) : 0.0f;
         cp.highContrastFactor = powf(highContrastMaxReduction, e);
     }
-    cp.lowContrastFactor = i < coarserLevelsStart ? powf(lowContrastMaxEnhancment, 1.0f - ((float)i / (float)coarserLevelsStart)) : 1.0f;
+    if (i >= coarserLevelsStart) cp.lowContrastFactor = 1.0f;
+    else if (t.linear_low_contrast) cp.lowContrastFactor = lowContrastMaxEnhancment - (float)i * ((lowContrastMaxEnhancment - 1.0f) / (float)coarserLevelsStart);   // :284-286
+    else cp.lowContrastFactor = powf(lowContrastMaxEnhancment, 1.0f - ((float)i / (float)coarserLevelsStart));   // :289-291
     return cp;
 }
 
 // src/vk_processing.cpp:321-325; the buffer bound to band level l is index l (:1518-1520).
-static musica_nr_params host_nr_params(uint32_t i) {
-    const float nrHighCnr = 9.0f, nrMaxHighFactor = 1.2f, nrLowCnr = 3.0f, nrMinLowFactor = 0.6f;  // vk_processing.h:39-42
+static musica_nr_params host_nr_params(uint32_t i, const musica_tunables& t) {
+    const float nrHighCnr = t.nr_high_cnr, nrMaxHighFactor = t.nr_max_high_factor, nrLowCnr = t.nr_low_cnr, nrMinLowFactor = t.nr_min_low_factor;  // vk_processing.h:39-42
     musica_nr_params q;
     q.highCnr = nrHighCnr;
     q.highFactor = nrMaxHighFactor - (nrMaxHighFactor - 1.0f) * ((float)i / (float)MUSICA_CNR_LEVEL);
@@ -277,10 +285,22 @@ void musica_destroy(musica_ctx* c) {
     delete c;
 }
 
-static musica_ctx* create_impl(const musica_params* params);
-musica_ctx* musica_create(const musica_params* params) {
+static musica_ctx* create_impl(const musica_params* params, const musica_tunables* tunables);
+void musica_tunables_default(musica_tunables* t) {
+    if (!t) return;
+    t->nr_high_cnr = 9.0f; t->nr_max_high_factor = 1.2f; t->nr_low_cnr = 3.0f; t->nr_min_low_factor = 0.6f;   // include/vk_processing.h:39-42
+    t->high_contrast_max_reduction = 0.2f; t->low_contrast_max_enhancement = 3.0f;                             // :48-49
+    t->linear_low_contrast = 0u; t->linear_high_contrast = 0u;                                                 // :16-17 (commented out)
+}
+int musica_get_tunables(const musica_ctx* c, musica_tunables* out) {
+    if (!c || !out) return fail("musica_get_tunables: NULL argument");
+    *out = c->tun;
+    return 1;
+}
+musica_ctx* musica_create(const musica_params* params) { return musica_create_ex(params, nullptr); }
+musica_ctx* musica_create_ex(const musica_params* params, const musica_tunables* tunables) {
     try {
-        return create_impl(params);
+        return create_impl(params, tunables);
     } catch (const std::exception& e) {
         fail("musica_create: %s", e.what());
     } catch (...) {
@@ -289,8 +309,17 @@ musica_ctx* musica_create(const musica_params* params) {
     return nullptr;
 }
 
-static musica_ctx* create_impl(const musica_params* params) {
+static musica_ctx* create_impl(const musica_params* params, const musica_tunables* tunables) {
     if (!params) { fail("musica_create: params is NULL"); return nullptr; }
+    musica_tunables tun;
+    musica_tunables_default(&tun);
+    if (tunables) {
+        tun = *tunables;
+        const float v[6] = {tun.nr_high_cnr, tun.nr_max_high_factor, tun.nr_low_cnr, tun.nr_min_low_factor, tun.high_contrast_max_reduction, tun.low_contrast_max_enhancement};
+        for (float x : v)
+            if (!(x == x) || x > 3.0e38f || x < -3.0e38f) { fail("musica_create_ex: a tunable is not a finite number"); return nullptr; }
+        if (tun.nr_high_cnr == tun.nr_low_cnr) { fail("musica_create_ex: nr_high_cnr == nr_low_cnr (the slope of linearFunction, noise_reduction.comp:28, divides by their difference)"); return nullptr; }
+    }
     const uint32_t N = params->image_size;
     // 16384: a level-0 f32 plane is then 1 GiB — the kernels address planes through buffer descriptors with 32-bit
     // byte offsets and use bit 31 as the "nothing to load" marker, so a plane must stay below 2 GiB
@@ -312,6 +341,7 @@ static musica_ctx* create_impl(const musica_params* params) {
 
     musica_ctx* c = new musica_ctx();
     c->p = *params;
+    c->tun = tun;
     c->N = (int)N; c->L = (int)L; c->B = params->batch ? (int)params->batch : 1;
     c->p.levels = L; c->p.batch = (uint32_t)c->B;
     c->ref_order = (params->flags & MUSICA_FLAG_REFERENCE_ORDER) ? 1 : 0;
@@ -333,8 +363,8 @@ static musica_ctx* create_impl(const musica_params* params) {
     }
     { uint32_t n = N; while (n % 8 == 0) n /= 8; c->min_chain_exact = (n == 1); }
     c->hist_cov = (int)(N / 512u) * 512;  // imageSize / histWorkgroupCoverage groups, src/vk_processing.cpp:2293-2295
-    for (int i = 0; i < c->L; i++) c->h_cparams[i] = host_contrast_params((uint32_t)i, L);
-    for (int i = 0; i < 3; i++) c->h_nr[i] = host_nr_params((uint32_t)i);
+    for (int i = 0; i < c->L; i++) c->h_cparams[i] = host_contrast_params((uint32_t)i, L, c->tun);
+    for (int i = 0; i < 3; i++) c->h_nr[i] = host_nr_params((uint32_t)i, c->tun);
     c->min_waves = 2048;
     c->expand_rows = env_int("MUSICA_EXPAND_ROWS", 8);
     c->sdev_rows = env_int("MUSICA_SDEV_ROWS", 32) & ~15;
@@ -1710,7 +1740,8 @@ static int pipeline_run(const std::vector<musica_ctx*>& use, uint32_t steps) {
     return 1;
 }
 
-musica_pipeline* musica_pipeline_create(const musica_params* params, uint32_t depth) {
+musica_pipeline* musica_pipeline_create(const musica_params* params, uint32_t depth) { return musica_pipeline_create_ex(params, depth, nullptr); }
+musica_pipeline* musica_pipeline_create_ex(const musica_params* params, uint32_t depth, const musica_tunables* tunables) {
     if (!params) { fail("musica_pipeline_create: params is NULL"); return nullptr; }
     if (depth < 1 || depth > 16) { fail("musica_pipeline_create: depth %u out of range [1, 16]", depth); return nullptr; }
     musica_pipeline* pl = nullptr;
@@ -1725,7 +1756,7 @@ musica_pipeline* musica_pipeline_create(const musica_params* params, uint32_t de
             // the contexts are identical: the launch geometry the first one tuned is copied to the others instead of tuned again
             musica_params qk = q;
             if (k > 0) qk.flags |= MUSICA_FLAG_NO_AUTOTUNE;
-            musica_ctx* c = musica_create(&qk);
+            musica_ctx* c = musica_create_ex(&qk, tunables);
             if (c && k > 0) { copy_rows(c, pl->ctx[0]); c->p.flags = q.flags; }
             if (!c) {
                 // the contexts beyond `depth` only exist for the queue calibration: without them (e.g. device memory is short at a

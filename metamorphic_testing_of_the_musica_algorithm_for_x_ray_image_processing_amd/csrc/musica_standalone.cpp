@@ -35,6 +35,8 @@ int main(int argc, char* argv[]) {
     int device = 0;
     const char* debugDir = nullptr;
     uint32_t flags = MUSICA_FLAG_NO_AUTOTUNE | MUSICA_FLAG_NO_GRAPH;
+    musica_tunables tun;   // the reference's #defines / constants (include/vk_processing.h:16-17, 39-49) as options
+    musica_tunables_default(&tun);
     if (const char* e = getenv("MUSICA_SIZE")) imageSize = (uint32_t)atoi(e);
     if (const char* e = getenv("MUSICA_LEVELS")) levels = (uint32_t)atoi(e);
 
@@ -48,6 +50,8 @@ int main(int argc, char* argv[]) {
         else if (!strcmp(argv[i], "--debug-dir") && i + 1 < argc) debugDir = argv[++i];
         else if (!strcmp(argv[i], "--reference-order")) flags |= MUSICA_FLAG_REFERENCE_ORDER;
         else if (!strcmp(argv[i], "--clahe")) flags |= MUSICA_FLAG_CLAHE;
+        else if (!strcmp(argv[i], "--linear-low-contrast")) tun.linear_low_contrast = 1;     // #define LINEAR_LOW_CONTRAST_LEVELS_REDUCTION
+        else if (!strcmp(argv[i], "--linear-high-contrast")) tun.linear_high_contrast = 1;   // #define LINEAR_HIGH_CONTRAST_LEVELS_REDUCTION
         else pos.push_back(argv[i]);
     }
     ASSERT_MSG(pos.size() == 2, "wrong number of arguments");  // main.cpp:37
@@ -66,7 +70,7 @@ int main(int argc, char* argv[]) {
     p.batch = 1;
     p.device = device;
     p.flags = flags;
-    musica_ctx* ctx = musica_create(&p);
+    musica_ctx* ctx = musica_create_ex(&p, &tun);
     ASSERT_MSG(ctx != nullptr, "failed to initialize vk processing");  // main.cpp:51 (message kept)
     const auto t0c = std::chrono::high_resolution_clock::now();
 

@@ -47,6 +47,24 @@ class Params(C.Structure):
                 ("device", C.c_int32), ("flags", C.c_uint32)]
 
 
+class Tunables(C.Structure):
+    """musica_tunables (include/musica.h): the constants of include/vk_processing.h:39-49 and the two LINEAR_* #defines of :16-17."""
+    _fields_ = [("nr_high_cnr", C.c_float), ("nr_max_high_factor", C.c_float), ("nr_low_cnr", C.c_float), ("nr_min_low_factor", C.c_float),
+                ("high_contrast_max_reduction", C.c_float), ("low_contrast_max_enhancement", C.c_float),
+                ("linear_low_contrast", C.c_uint32), ("linear_high_contrast", C.c_uint32)]
+
+
+def default_tunables(**overrides):
+    """The reference's values, with keyword overrides (e.g. linear_low_contrast=1, nr_low_cnr=2.5)."""
+    t = Tunables()
+    load_library().musica_tunables_default(C.byref(t))
+    for k, v in overrides.items():
+        if k not in dict(Tunables._fields_):
+            raise KeyError(k)
+        setattr(t, k, v)
+    return t
+
+
 class HistMaxPoint(C.Structure):
     _fields_ = [("maxValue", C.c_uint32), ("maxBin", C.c_uint32)]
 
@@ -165,6 +183,10 @@ ABI = {
     "musica_pipeline_sync": (C.c_int, [_VP]),
     "musica_last_error": (C.c_char_p, []),
     "musica_abi_version": (C.c_uint32, []),
+    "musica_create_ex": (_VP, [C.POINTER(Params), C.POINTER(Tunables)]),
+    "musica_tunables_default": (None, [C.POINTER(Tunables)]),
+    "musica_get_tunables": (C.c_int, [_VP, C.POINTER(Tunables)]),
+    "musica_pipeline_create_ex": (_VP, [C.POINTER(Params), C.c_uint32, C.POINTER(Tunables)]),
     "musica_device_count": (C.c_int, []),
 }
 
@@ -224,12 +246,13 @@ class MusicaProcessing:
         return self
 
     # ---- the reference's interface -------------------------------------------------
-    def init(self, imageSize, outImageViews=None, levels=0, batch=1, flags=0):
-        """bool init(uint32_t imageSize, std::vector<VkImageView>*) — src/vk_processing.cpp:1984-2020."""
+    def init(self, imageSize, outImageViews=None, levels=0, batch=1, flags=0, tunables=None):
+        """bool init(uint32_t imageSize, std::vector<VkImageView>*) — src/vk_processing.cpp:1984-2020.
+        tunables: a Tunables (default_tunables(...)) — the reference's compile-time constants as runtime values; None = the reference's."""
         if self._h:
             self.cleanup()
         p = Params(int(imageSize), int(levels), int(batch), self._device, int(flags))
-        h = self._lib.musica_create(C.byref(p))
+        h = self._lib.musica_create_ex(C.byref(p), C.byref(tunables) if tunables is not None else None)
         if not h:
             return False
         self._h = h
@@ -391,6 +414,11 @@ class MusicaProcessing:
         c = GradCurve()
         self._ok(self._lib.musica_get_grad_curve(self._h, image_index, C.byref(c)), "musica_get_grad_curve")
         return c.as_array(), (c.t0, c.ta, c.t1)
+
+    def tunables(self):
+        t = Tunables()
+        self._ok(self._lib.musica_get_tunables(self._h, C.byref(t)), "musica_get_tunables")
+        return t
 
     def contrast_params(self, level):
         p = ContrastParams()

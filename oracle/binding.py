@@ -94,6 +94,14 @@ def lib():
     vp = C.c_void_p
     L.musica_oracle_create.restype = vp
     L.musica_oracle_create.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
+    L.musica_oracle_create_ex.restype = vp
+    L.musica_oracle_create_ex.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, vp]
+    L.musica_oracle_tunables_default.restype = None
+    L.musica_oracle_tunables_default.argtypes = [vp]
+    L.musica_oracle_host_contrast_params_ex.restype = ContrastParams
+    L.musica_oracle_host_contrast_params_ex.argtypes = [C.c_uint32, C.c_uint32, vp]
+    L.musica_oracle_host_nr_params_ex.restype = NrParams
+    L.musica_oracle_host_nr_params_ex.argtypes = [C.c_uint32, vp]
     L.musica_oracle_destroy.argtypes = [vp]
     L.musica_oracle_set_threads.argtypes = [C.c_int]
     L.musica_oracle_get_threads.restype = C.c_int
@@ -189,9 +197,10 @@ def set_threads(n):
 class Oracle:
     """One image through VulkanProcessing::execute, restated on the CPU."""
 
-    def __init__(self, image_size, levels=0, order=ORDER_FAST, flags=0):
+    def __init__(self, image_size, levels=0, order=ORDER_FAST, flags=0, tunables=None):
+        """tunables: a ctypes structure with musica_tunables' layout (include/musica.h; e.g. processing.Tunables or binding.Tunables); None = the reference's constants."""
         self.L = lib()
-        self.h = self.L.musica_oracle_create(image_size, levels, order, flags)
+        self.h = self.L.musica_oracle_create_ex(image_size, levels, order, flags, C.cast(C.byref(tunables), C.c_void_p) if tunables is not None else None)
         if not self.h:
             raise ValueError("musica_oracle_create(%d, %d) failed" % (image_size, levels))
         self.N = image_size
@@ -464,13 +473,36 @@ def get_y(points_xy, x):
     return lib().musica_oracle_get_y(pts, len(points_xy), x)
 
 
-def host_contrast_params(level, levels):
-    p = lib().musica_oracle_host_contrast_params(level, levels)
+class Tunables(C.Structure):
+    """musica_tunables (include/musica.h)."""
+    _fields_ = [("nr_high_cnr", C.c_float), ("nr_max_high_factor", C.c_float), ("nr_low_cnr", C.c_float), ("nr_min_low_factor", C.c_float),
+                ("high_contrast_max_reduction", C.c_float), ("low_contrast_max_enhancement", C.c_float),
+                ("linear_low_contrast", C.c_uint32), ("linear_high_contrast", C.c_uint32)]
+
+
+def default_tunables(**overrides):
+    t = Tunables()
+    lib().musica_oracle_tunables_default(C.cast(C.byref(t), C.c_void_p))
+    for k, v in overrides.items():
+        if k not in dict(Tunables._fields_):
+            raise KeyError(k)
+        setattr(t, k, v)
+    return t
+
+
+def host_contrast_params(level, levels, tunables=None):
+    if tunables is None:
+        p = lib().musica_oracle_host_contrast_params(level, levels)
+    else:
+        p = lib().musica_oracle_host_contrast_params_ex(level, levels, C.cast(C.byref(tunables), C.c_void_p))
     return (p.lowContrastFactor, p.highContrastFactor)
 
 
-def host_nr_params(i):
-    p = lib().musica_oracle_host_nr_params(i)
+def host_nr_params(i, tunables=None):
+    if tunables is None:
+        p = lib().musica_oracle_host_nr_params(i)
+    else:
+        p = lib().musica_oracle_host_nr_params_ex(i, C.cast(C.byref(tunables), C.c_void_p))
     return (p.lowCnr, p.lowFactor, p.highCnr, p.highFactor)
 
 

@@ -611,32 +611,55 @@ void musica_oracle_k_clahe_grad_curve_apply(const float* in, uint32_t side, cons
 
 /* ---- host parameter formulas ------------------------------------------ */
 
-/* src/vk_processing.cpp:259-293 (non-LINEAR branches; tunables vk_processing.h:44-49) */
-musica_contrast_params musica_oracle_host_contrast_params(uint32_t i, uint32_t levels) {
+/* include/vk_processing.h:39-49 and the two #defines of :16-17, as data (musica_tunables, include/musica.h) */
+void musica_oracle_tunables_default(musica_tunables* t) {
+    t->nr_high_cnr = 9.0f; t->nr_max_high_factor = 1.2f; t->nr_low_cnr = 3.0f; t->nr_min_low_factor = 0.6f;
+    t->high_contrast_max_reduction = 0.2f; t->low_contrast_max_enhancement = 3.0f;
+    t->linear_low_contrast = 0u; t->linear_high_contrast = 0u;
+}
+
+/* src/vk_processing.cpp:259-293, every branch (tunables vk_processing.h:44-49) */
+musica_contrast_params musica_oracle_host_contrast_params_ex(uint32_t i, uint32_t levels, const musica_tunables* t) {
     const uint32_t coarserLevelsStart = MUSICA_COARSER_LEVELS_START;
-    const float highContrastMaxReduction = 0.2f, lowContrastMaxEnhancment = 3.0f;
+    const float highContrastMaxReduction = t->high_contrast_max_reduction, lowContrastMaxEnhancment = t->low_contrast_max_enhancement;
     musica_contrast_params cp;
     uint32_t coarserLevelsCount = levels - coarserLevelsStart;
     if (i < coarserLevelsStart) cp.highContrastFactor = 1.0f;
-    else {
+    else if (t->linear_high_contrast) {                                 /* #ifdef LINEAR_HIGH_CONTRAST_LEVELS_REDUCTION, :263-268 */
+        cp.highContrastFactor = coarserLevelsCount > 1
+            ? 1.0f - (float)(i - coarserLevelsStart) * (1.0f - highContrastMaxReduction) / (float)(levels - coarserLevelsStart - 1)
+            : 1.0f;                                                     /* 0 / 0 at L = 4: taken as "no reduction" (the power form's exponent 0) */
+    } else {
         float e = coarserLevelsCount > 1 ? (float)(i - coarserLevelsStart) / (float)(coarserLevelsCount - 1) : 0.0f;
         cp.highContrastFactor = powf(highContrastMaxReduction, e);     /* :270-274 */
     }
-    cp.lowContrastFactor = i < coarserLevelsStart
-        ? powf(lowContrastMaxEnhancment, 1.0f - ((float)i / (float)coarserLevelsStart)) /* :288-292 */
-        : 1.0f;
+    if (i >= coarserLevelsStart) cp.lowContrastFactor = 1.0f;
+    else if (t->linear_low_contrast)                                    /* #ifdef LINEAR_LOW_CONTRAST_LEVELS_REDUCTION, :282-287 */
+        cp.lowContrastFactor = lowContrastMaxEnhancment - (float)i * ((lowContrastMaxEnhancment - 1.0f) / (float)coarserLevelsStart);
+    else
+        cp.lowContrastFactor = powf(lowContrastMaxEnhancment, 1.0f - ((float)i / (float)coarserLevelsStart)); /* :288-292 */
     return cp;
+}
+musica_contrast_params musica_oracle_host_contrast_params(uint32_t i, uint32_t levels) {
+    musica_tunables t;
+    musica_oracle_tunables_default(&t);
+    return musica_oracle_host_contrast_params_ex(i, levels, &t);
 }
 
 /* src/vk_processing.cpp:321-325 (tunables vk_processing.h:39-42) */
-musica_nr_params musica_oracle_host_nr_params(uint32_t i) {
-    const float nrHighCnr = 9.0f, nrMaxHighFactor = 1.2f, nrLowCnr = 3.0f, nrMinLowFactor = 0.6f;
+musica_nr_params musica_oracle_host_nr_params_ex(uint32_t i, const musica_tunables* t) {
+    const float nrHighCnr = t->nr_high_cnr, nrMaxHighFactor = t->nr_max_high_factor, nrLowCnr = t->nr_low_cnr, nrMinLowFactor = t->nr_min_low_factor;
     musica_nr_params p;
     p.highCnr = nrHighCnr;
     p.highFactor = nrMaxHighFactor - (nrMaxHighFactor - 1.0f) * ((float)i / (float)MUSICA_CNR_LEVEL);
     p.lowCnr = nrLowCnr;
     p.lowFactor = nrMinLowFactor + (1.0f - nrMinLowFactor) * ((float)i / (float)MUSICA_CNR_LEVEL);
     return p;
+}
+musica_nr_params musica_oracle_host_nr_params(uint32_t i) {
+    musica_tunables t;
+    musica_oracle_tunables_default(&t);
+    return musica_oracle_host_nr_params_ex(i, &t);
 }
 
 /* ---- whole pipeline --------------------------------------------------- */
@@ -684,7 +707,11 @@ struct musica_oracle {
 
 static float* zalloc(uint32_t side) { return (float*)calloc((size_t)side * side, sizeof(float)); }
 
-musica_oracle* musica_oracle_create(uint32_t N, uint32_t levels, int order, uint32_t flags) {
+musica_oracle* musica_oracle_create(uint32_t N, uint32_t levels, int order, uint32_t flags) { return musica_oracle_create_ex(N, levels, order, flags, NULL); }
+musica_oracle* musica_oracle_create_ex(uint32_t N, uint32_t levels, int order, uint32_t flags, const musica_tunables* tunables) {
+    musica_tunables tun;
+    musica_oracle_tunables_default(&tun);
+    if (tunables) tun = *tunables;
     if (N < 16) return NULL;
     uint32_t Lref = 0;
     while ((1u << Lref) < N) Lref++;                                   /* ceil(log2 N), src/vk_processing.cpp:1989 */
@@ -707,11 +734,11 @@ musica_oracle* musica_oracle_create(uint32_t N, uint32_t levels, int order, uint
         o->exp_up[i] = zalloc(o->S[i]);
         o->exp_low[i] = zalloc(o->S[i]);
         o->expand[i] = zalloc(o->S[i]);
-        o->cparams[i] = musica_oracle_host_contrast_params(i, L);
+        o->cparams[i] = musica_oracle_host_contrast_params_ex(i, L, &tun);
     }
     for (uint32_t i = 0; i < 3; i++) {
         o->nr_band[i] = zalloc(o->S[i]);
-        o->nr[i] = musica_oracle_host_nr_params(i);
+        o->nr[i] = musica_oracle_host_nr_params_ex(i, &tun);
     }
     o->cnr = zalloc(o->S[MUSICA_CNR_LEVEL]);
     o->relevant = zalloc(N);

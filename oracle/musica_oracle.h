@@ -47,6 +47,9 @@ typedef struct musica_oracle musica_oracle;
 
 /* levels == 0 => ceil(log2 N) as src/vk_processing.cpp:1989. */
 musica_oracle* musica_oracle_create(uint32_t image_size, uint32_t levels, int order, uint32_t flags);
+/* the same with the parameter formulas' constants given (NULL: the reference's, include/vk_processing.h:16-17, 39-49) */
+musica_oracle* musica_oracle_create_ex(uint32_t image_size, uint32_t levels, int order, uint32_t flags, const musica_tunables* tunables);
+void musica_oracle_tunables_default(musica_tunables* out);
 void musica_oracle_destroy(musica_oracle* o);
 /* Number of OpenMP threads used by the oracle's loops (1 = scalar port). */
 void musica_oracle_set_threads(int n);
@@ -138,6 +141,8 @@ void musica_oracle_k_clahe_grad_curve_apply(const float* in, uint32_t side, cons
 /* Host parameter formulas of initMemory (src/vk_processing.cpp:259-297, 321-325). */
 musica_contrast_params musica_oracle_host_contrast_params(uint32_t level, uint32_t levels);
 musica_nr_params musica_oracle_host_nr_params(uint32_t i);
+musica_contrast_params musica_oracle_host_contrast_params_ex(uint32_t level, uint32_t levels, const musica_tunables* t);
+musica_nr_params musica_oracle_host_nr_params_ex(uint32_t i, const musica_tunables* t);
 
 #ifdef __cplusplus
 }

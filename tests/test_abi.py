@@ -23,7 +23,7 @@ def _declared_symbols():
 def test_library_is_built_and_loads():
     assert os.path.exists(mp.LIB_PATH), "run build() first: libmusica_hip.so missing"
     lib = mp.load_library()
-    assert lib.musica_abi_version() == 2
+    assert lib.musica_abi_version() == 3
 
 
 def test_exports_every_declared_symbol():
@@ -43,6 +43,7 @@ def test_struct_sizes_match_reference_layouts():
     assert ctypes.sizeof(mp.HistMaxPoint) == 8
     assert ctypes.sizeof(mp.ContrastParams) == 8
     assert ctypes.sizeof(mp.NrParams) == 16
+    assert ctypes.sizeof(mp.Tunables) == 32      # musica_tunables: six floats + two uint32 (ABI version 3)
 
 
 def test_no_cpu_fallback_without_gpu():

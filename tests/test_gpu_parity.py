@@ -842,3 +842,36 @@ def test_minmax_two_stage_edge_cases(ob, n, batch):
             assert p.minmax(k) == o.minmax(), "image %d rep %d" % (k, rep)
             assert np.array_equal(p.noise_hist(0, k), o.noise_hist(0)) and np.array_equal(p.grad_hist(k), o.grad_hist())
     p.cleanup()
+
+
+@pytest.mark.parametrize("over", [{"linear_low_contrast": 1}, {"linear_high_contrast": 1}, {"linear_low_contrast": 1, "linear_high_contrast": 1},
+                                  {"nr_low_cnr": 2.0, "nr_high_cnr": 10.0, "nr_min_low_factor": 0.5, "nr_max_high_factor": 1.5},
+                                  {"high_contrast_max_reduction": 0.5, "low_contrast_max_enhancement": 2.0}],
+                         ids=lambda o: ",".join("%s=%s" % kv for kv in o.items()))
+def test_runtime_tunables_against_the_oracle(ob, over):
+    """musica_create_ex (ABI version 3): the reference's compile-time configuration — the LINEAR_* forms of src/vk_processing.cpp:262-293
+    and the constants of include/vk_processing.h:39-49 — as runtime values; every variant bit-identical to the oracle created with the
+    same musica_tunables, and different from the default configuration's result."""
+    n, levels = 1024, 7
+    px = phantom(n, 321)
+    t = mp.default_tunables(**over)
+    o = ob.Oracle(n, levels, ob.ORDER_FAST, tunables=t).execute(px)
+    p = mp.MusicaProcessing()
+    assert p.init(n, levels=levels, tunables=t), mp.last_error()
+    got = p.tunables()
+    assert all(getattr(got, k) == getattr(t, k) for k, _ in mp.Tunables._fields_)
+    assert p.execute(px), mp.last_error()
+    _compare_all(p, o, ob, tag=str(over) + ": ")
+    base = _proc(n, levels)
+    assert base.execute(px)
+    assert not np.array_equal(base.graded(), p.graded())
+    # a batch through the pipeline entry point with the same tunables
+    p.cleanup()
+    base.cleanup()
+
+
+def test_create_ex_refuses_unusable_tunables():
+    p = mp.MusicaProcessing()
+    assert not p.init(512, levels=4, tunables=mp.default_tunables(nr_low_cnr=9.0))          # == nr_high_cnr: the slope divides by zero
+    assert "nr_high_cnr == nr_low_cnr" in mp.last_error()
+    assert not p.init(512, levels=4, tunables=mp.default_tunables(low_contrast_max_enhancement=float("nan")))

@@ -122,35 +122,90 @@ def _distribution(p, q, levels):
     return d
 
 
+# The contract between the default (separable) order and the literal one, frozen in round 4 (DESIGN.md section 2 has the derivations):
+#   u = 2^-24 (one f32 rounding of a result below 2), M = max |normalized| of the image (>= every partial sum of the non-negative taps).
+#   * smooth + downsample, one level: literal = 25 x (2 roundings per product) + 24 additions <= 26 u M from the exact sum; separable =
+#     (5 products + 4 additions) twice, the vertical error passed on with weight sum(w) = 1 <= 10 u M.  => |default - literal| <= 36 u M per
+#     level, and level i inherits the difference of its input with weight 1: downsampled[i] <= 36 (i + 1) u M.
+#   * band-pass[i] = fine[i] - lowpass(coarse[i]): the inputs' differences (36 i u M and 36 (i + 1) u M), the zero-inserted stencil's own
+#     26 + 10 roundings, two for the subtraction: <= (72 i + 74) u M.
+#   * sdev[i]: the RMS of 25 values is 1-Lipschitz in the max-norm => band bound + 28 u M for its own 25 squares, 24 additions, /25 and sqrt.
+#   * reconstruction: the literal linearFunction (noise_reduction.comp:24-31) jumps by 3 m at cnr 3 and 9, m = (highFactor - lowFactor) / 6:
+#     a cnr texel whose class (< 3, [3, 9], > 9) differs between the two orders moves the texels under it by up to
+#     3 m_0 max|band_0 gain_0| + 3 m_1 max|band_1 gain_1|; every texel that is not within reach of such a cnr texel (its 8 x 8 block at
+#     level 0 / the 4 x 4 block at level 1, plus the 5-tap stencils' reach) differs by rounding only.
+# The MEASURED distribution of round 3 is a committed artefact (tests/golden/literal_order_distribution.json); the test holds this
+# build to it with the slack stated below, so a number that moves is a finding — the assertions are no longer edited to follow it.
+U24 = 2.0 ** -24
+GOLDEN_DIST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "literal_order_distribution.json")
+SLACK_MAX = 2.0       # maxima of rounding-type quantities may reach 2 x the committed value (they are a few ulp: one more is +15 - 50 %)
+SLACK_FRACTION = 4.0  # fractions of rare events (histogram counts in another bin, texels above a threshold, differing 8-bit pixels)
+FLOOR_FRACTION = 2e-6
+
+
+def _nr_class(c):
+    return np.where(c < 3.0, 0, np.where(c > 9.0, 2, 1))
+
+
+def _near_jump_mask(p, q, n):
+    """True where a level-0 texel can be reached by a cnr texel whose noise-reduction class differs between the two contexts:
+    its 8 x 8 block (level 0, scale 8) or 4 x 4 block at level 1 (= 8 x 8 at level 0), grown by the stencils' reach."""
+    cp, cq = p.image(mp.IMG_CNR, 3) * np.float32(256.0), q.image(mp.IMG_CNR, 3) * np.float32(256.0)
+    differ = _nr_class(cp) != _nr_class(cq)
+    if not differ.any():
+        return np.zeros((n, n), dtype=bool)
+    scale = int(np.ceil(n / differ.shape[0]))
+    big = np.kron(differ, np.ones((scale, scale), dtype=bool))[:n, :n]
+    reach = 8      # level-1 band rows reach 2 coarse = 4 fine texels through expand 1, + 2 through expand 0; rounded up
+    from scipy.ndimage import maximum_filter
+    return maximum_filter(big, size=2 * reach + 1)
+
+
 @pytest.mark.parametrize("name,n,levels,seed,bits,flags", CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_default_order_against_literal_order_distribution(name, n, levels, seed, bits, flags):
-    """Bounds asserted (and quoted in DESIGN.md section 2 / bench.py's `parity` string):
-    every stencil output within 6e-7 (downsampled: 7 ulp at 1.0 measured at 4096^2) / 1e-6 (band-pass, sdev); every noise-histogram argmax within one bin and
-    at most 1 % of a histogram's counts in a different bin; reconstruction: max 5e-2 (a block under a cnr texel that sits
-    within rounding distance of the noise-reduction thresholds 3 / 9, noise_reduction.comp:24-31: measured 2.1e-2 at configs[4]); with all four argmax equal at most
-    0.02 % of the texels above 4e-6 and at most 0.1 % of the 8-bit pixels different; with an argmax one bin apart (the
-    curve abscissae move by 1 / 2048 * 0.1 * ...) at most 0.1 % of the texels above 2e-3 and at most 1 % of the 8-bit
-    pixels off by more than one grey level."""
     px = phantom(n, seed, bits=bits)
     p = _proc(n, levels, flags=flags)
     q = _proc(n, levels, flags=flags | mp.FLAG_REFERENCE_ORDER)
     assert p.execute(px) and q.execute(px), mp.last_error()
     L = p.pyramidLevels
-    _same(p.image(mp.IMG_NORMALIZED), q.image(mp.IMG_NORMALIZED), "normalized")    # no stencil before this image
+    norm = p.image(mp.IMG_NORMALIZED)
+    _same(norm, q.image(mp.IMG_NORMALIZED), "normalized")    # no stencil before this image
+    M = max(1.0, float(np.abs(norm).max()))
+    # ---- derived bounds, per level
+    for i in range(L):
+        dd = float(np.abs(p.image(mp.IMG_DOWNSAMPLED, i) - q.image(mp.IMG_DOWNSAMPLED, i)).max())
+        db = float(np.abs(p.image(mp.IMG_BANDPASS, i) - q.image(mp.IMG_BANDPASS, i)).max())
+        assert dd <= 36 * (i + 1) * U24 * M, (name, "downsampled", i, dd)
+        assert db <= (72 * i + 74) * U24 * M, (name, "bandpass", i, db)
+        if i < 4:
+            ds = float(np.abs(p.image(mp.IMG_SDEV, i) - q.image(mp.IMG_SDEV, i)).max())
+            assert ds <= (72 * i + 74 + 28) * U24 * M, (name, "sdev", i, ds)
     d = _distribution(p, q, L)
     print("LITERAL_ORDER_DISTRIBUTION %s %s" % (name, json.dumps(d)))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "literal_order_%s.json" % name), "w") as f:
             json.dump(d, f, indent=1)
-    assert d["downsampled_max"] <= 6e-7 and d["bandpass_max"] <= 1e-6 and d["sdev_max"] <= 1e-6
-    assert max(d["argmax_shift"]) <= 1 and d["noise_hist_moved_fraction"] <= 0.01
-    assert d["recon_max"] <= 5e-2      # 0.3 x |contrast-enhanced band| under a cnr texel that crosses 3 or 9 (measured: 2.1e-2 at configs[4])
-    if max(d["argmax_shift"]) == 0:
-        assert d["recon_frac_above_4e-6"] <= 2e-4
-        assert d["out8_frac_differ"] <= 1e-3
-    else:
-        assert d["recon_frac_above_2e-3"] <= 1e-3
-        assert d["out8_frac_differ_by_more_than_1"] <= 1e-2
+    # ---- the block jumps of the literal linearFunction: every large reconstruction difference sits within reach of a cnr texel whose class
+    # differs, and is no larger than the jump allows
+    rec = np.abs(p.image(mp.IMG_EXPAND, 0) - q.image(mp.IMG_EXPAND, 0))
+    near = _near_jump_mask(p, q, n)
+    jump = 0.0
+    for lvl in (0, 1):
+        lo_c, lo_f, hi_c, hi_f = q.nr_params(lvl)
+        m = (hi_f - lo_f) / (hi_c - lo_c)
+        jump += 3.0 * m * float(np.abs(q.image(mp.IMG_EXP_BANDPASS, lvl)).max())
+    rounding = 21000 * U24 * M     # sum over 12 levels of (36 + 3.6 (72 i + 74)) u M: contrast gain <= 3, noise-reduction factor <= 1.2
+    assert float(rec[~near].max() if (~near).any() else 0.0) <= rounding, (name, "reconstruction away from every class change", float(rec[~near].max()))
+    assert d["recon_max"] <= jump + rounding, (name, "reconstruction under a class change", d["recon_max"], jump)
+    assert max(d["argmax_shift"]) <= 1
+    # ---- the committed distribution (tests/golden/literal_order_distribution.json), with the slack stated above
+    want = json.load(open(GOLDEN_DIST))[name]
+    for key in ("downsampled_max", "bandpass_max", "sdev_max", "recon_p9998"):
+        assert d[key] <= SLACK_MAX * want[key] + 1e-9, (name, key, d[key], want[key])
+    for key in ("noise_hist_moved_fraction", "recon_frac_above_4e-6", "recon_frac_above_2e-3", "out8_frac_differ", "out8_frac_differ_by_more_than_1"):
+        assert d[key] <= SLACK_FRACTION * want[key] + FLOOR_FRACTION, (name, key, d[key], want[key])
+    assert d["argmax_shift"] == want["argmax_shift"], (name, d["argmax_shift"], want["argmax_shift"])
+    assert d["grad_window_default"] == want["grad_window_default"] and d["grad_window_literal"] == want["grad_window_literal"]
     p.cleanup()
     q.cleanup()
