@@ -158,6 +158,10 @@ def measure_metric_traffic(timeout=90):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
+    # never start a profiler from under a profiler: the child would inherit the outer tool's preload environment, and a launcher that
+    # execs its target with a profiler library preloaded is the exec-after-GPU-init pattern this pool forbids (round-3 advisory)
+    if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "already under a profiler"
     target = os.path.join(ROOT, "devtools", "pmc_metric_target.py")
     got = {}
     td = tempfile.mkdtemp(prefix="musica_pmc_")

@@ -103,6 +103,9 @@ typedef struct musica_stats {
                                         graph, whatever the workload: for contexts that run beside other contexts on one GPU (each then owns
                                         one stream = one hardware queue; musica_pipeline_* alternates steps over three of them) */
 #define MUSICA_FLAG_NO_AUTOTUNE 0x8u /* skip the init-time launch-geometry autotune (rows per wavefront stay heuristic) */
+#define MUSICA_FLAG_ONE_SHOT   0x40u /* the context will execute once or a few times (musica-standalone: one image per process): no autotune, no graph
+                                        capture, ONE stream whatever the workload (creating a second stream costs more than one step saves).
+                                        Implies NO_AUTOTUNE and NO_GRAPH; those two flags on their own do NOT change the number of streams. */
 #define MUSICA_FLAG_REFERENCE_ORDER 0x20u /* the shaders' literal arithmetic order: img_smooth.comp:32-45, img_smooth_upsampled.comp:32-45
                                         (with the * 4.0 per tap) and img_sdev.comp:17-30 accumulate their 25 taps m (x) outer,
                                         n (y) inner, starting from 0. One thread per texel (as the shaders run), several times

@@ -71,6 +71,59 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def check_isa():
+    """What the kernels rely on in the generated code, read back from the built objects (llvm-objdump of the gfx950 code object):
+      * the cross-workgroup hand-offs of k_minmax_u16 and k_grad_recount_curve store their slot / read the slots with `sc1` (write-through
+        store, L1-bypassing load: kernels_analysis.hip / kernels_gradation.hip rely on that instead of an agent-scope fence);
+      * the ticket adds are returning agent-scope atomics (`sc0` = return value on gfx950's global_atomic_add).
+    Returns a dict of findings; raises RuntimeError when one is missing (tests/test_abi.py runs it: a compiler that weakens the relaxed
+    agent-scope accesses would otherwise only show up as a rare stale min / max)."""
+    import glob
+    import shutil
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        raise RuntimeError("llvm-objdump not found under /opt/rocm/lib/llvm/bin")
+    found = {}
+    td = tempfile.mkdtemp(prefix="musica_isa_")
+    try:
+        for src, kernel in (("kernels_analysis", "k_minmax_u16"), ("kernels_gradation", "k_grad_recount_curve")):
+            obj = os.path.join(HERE, "build", src + ".o")
+            if not os.path.exists(obj):
+                raise RuntimeError("%s is not built" % obj)
+            copy = os.path.join(td, src + ".o")
+            shutil.copy(obj, copy)
+            subprocess.run([objdump, "--offloading", copy], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=td)   # writes <copy>.0.hipv4-...gfx950
+            outs = glob.glob(copy + ".*gfx950")
+            if not outs:
+                raise RuntimeError("no gfx950 code object inside %s" % obj)
+            text = subprocess.run([objdump, "-d", outs[0]], check=True, stdout=subprocess.PIPE, text=True).stdout
+            body, inside = [], False
+            for line in text.splitlines():
+                if line.endswith(">:"):
+                    inside = kernel in line
+                elif inside:
+                    body.append(line)
+            code = "\n".join(body)
+            found[kernel] = {
+                "sc1_stores": sum(1 for l in body if "global_store_dword" in l and " sc1" in l),
+                "sc1_loads": sum(1 for l in body if "global_load_dword" in l and " sc1" in l),
+                "returning_atomic_adds": sum(1 for l in body if "global_atomic_add" in l and " sc0" in l),
+            }
+            if not code:
+                raise RuntimeError("%s: no code found for %s" % (src, kernel))
+        mm = found["k_minmax_u16"]
+        if mm["sc1_stores"] < 1 or mm["sc1_loads"] < 1 or mm["returning_atomic_adds"] < 1:
+            raise RuntimeError("k_minmax_u16's slot hand-off lost its sc1 store / sc1 load / returning ticket add: %r" % (mm,))
+        gr = found["k_grad_recount_curve"]
+        if gr["returning_atomic_adds"] < 1 or gr["sc1_loads"] < 1:
+            raise RuntimeError("k_grad_recount_curve's last-ticket hand-off lost its returning ticket add / sc1 histogram loads: %r" % (gr,))
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    return found
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
     print(LIB)
+    print(check_isa())

@@ -341,6 +341,8 @@ static musica_ctx* create_impl(const musica_params* params, const musica_tunable
 
     musica_ctx* c = new musica_ctx();
     c->p = *params;
+    if (c->p.flags & MUSICA_FLAG_ONE_SHOT) c->p.flags |= MUSICA_FLAG_NO_AUTOTUNE | MUSICA_FLAG_NO_GRAPH;
+    params = &c->p;
     c->tun = tun;
     c->N = (int)N; c->L = (int)L; c->B = params->batch ? (int)params->batch : 1;
     c->p.levels = L; c->p.batch = (uint32_t)c->B;
@@ -386,11 +388,10 @@ static musica_ctx* create_impl(const musica_params* params, const musica_tunable
     //    0.319, 8192^2 L10 0.747 / 0.779, 4 x 2048^2 0.264 / 0.263 (three streams: 0.287), 2 x 4096^2 0.433 / 0.457 (0.451), 8 x 2048^2
     //    0.434 / 0.443 (0.431)); one image with a pyramid of 11 or more levels: eager (3072^2 L12 0.214 against 0.220 as a graph and
     //    0.240 on one stream, 4096^2 L12 0.277 / 0.292 / 0.308);
-    //  * one-shot contexts (MUSICA_FLAG_NO_AUTOTUNE | MUSICA_FLAG_NO_GRAPH: musica-standalone): one stream — creating a second one
-    //    costs more than one step saves;
+    //  * one-shot contexts (MUSICA_FLAG_ONE_SHOT: musica-standalone): one stream — creating a second one costs more than one step saves;
     //  (The three-stream script and the image groups of rounds 1 - 3 won nowhere by more than noise at the end of round 3 and left in round 4.)
     const bool lone = !(params->flags & MUSICA_FLAG_LINEAR);
-    const bool one_shot = (params->flags & MUSICA_FLAG_NO_AUTOTUNE) && (params->flags & MUSICA_FLAG_NO_GRAPH);
+    const bool one_shot = (params->flags & MUSICA_FLAG_ONE_SHOT) != 0;
     const bool small_step = c->B == 1 ? N < 2048 : (size_t)c->B * N * N <= (size_t)3072 * 3072;
     c->dag = !lone ? 0 : (env_int("MUSICA_STREAMS", (small_step || one_shot) ? 1 : 2) >= 2 ? 2 : 0);
     c->use_graph = !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", (lone && (small_step || (c->B == 1 && L >= 11))) ? 0 : 1) != 0;

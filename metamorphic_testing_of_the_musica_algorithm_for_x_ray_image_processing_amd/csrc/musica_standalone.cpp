@@ -34,7 +34,7 @@ int main(int argc, char* argv[]) {
     uint32_t levels = 0;        // ceil(log2 N), src/vk_processing.cpp:1989
     int device = 0;
     const char* debugDir = nullptr;
-    uint32_t flags = MUSICA_FLAG_NO_AUTOTUNE | MUSICA_FLAG_NO_GRAPH;
+    uint32_t flags = MUSICA_FLAG_ONE_SHOT;   // one execute per process: no autotune, no graph capture, one stream
     musica_tunables tun;   // the reference's #defines / constants (include/vk_processing.h:16-17, 39-49) as options
     musica_tunables_default(&tun);
     if (const char* e = getenv("MUSICA_SIZE")) imageSize = (uint32_t)atoi(e);

@@ -32,6 +32,7 @@ FLAG_GENERIC_KERNELS = 0x4
 FLAG_NO_AUTOTUNE = 0x8
 FLAG_LINEAR = 0x10
 FLAG_REFERENCE_ORDER = 0x20
+FLAG_ONE_SHOT = 0x40
 
 IMG_NORMALIZED, IMG_DOWNSAMPLED, IMG_BANDPASS, IMG_SDEV, IMG_CNR, IMG_EXPAND = 0, 1, 2, 3, 4, 5
 IMG_GRADED, IMG_RELEVANT, IMG_LOWPASS, IMG_EXP_BANDPASS, IMG_SQRT, IMG_CLAHE_GRADED, IMG_CONTRAST_BAND = 6, 7, 8, 9, 10, 11, 12

@@ -110,3 +110,14 @@ def test_cli_error_contract(tmp_path):
         raw.write_bytes(bytes(256 + 2 * 64 * 64))
         r = subprocess.run([mp.CLI_PATH, str(raw), str(tmp_path / "o.bmp"), "--size", "64"], capture_output=True, text=True)
         assert r.returncode == 1 and "MAIN ERROR" in r.stderr
+
+
+def test_generated_code_keeps_the_cross_workgroup_hand_offs():
+    """build.check_isa(): the slot hand-off of k_minmax_u16 and the last-ticket hand-off of k_grad_recount_curve rely on sc1 (write-through /
+    L1-bypassing) accesses and returning ticket adds in the generated code rather than on agent-scope fences; read them back from the
+    built code objects so that a compiler change that weakens the relaxed agent-scope accesses fails here, not as a rare stale min / max."""
+    from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd import build
+    build.build()
+    found = build.check_isa()
+    assert found["k_minmax_u16"]["sc1_stores"] >= 1 and found["k_minmax_u16"]["sc1_loads"] >= 1
+    assert found["k_grad_recount_curve"]["returning_atomic_adds"] >= 1

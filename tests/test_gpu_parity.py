@@ -145,7 +145,7 @@ def test_default_dispatch_per_workload(monkeypatch):
     for v in ("MUSICA_STREAMS", "MUSICA_GRAPH"):
         monkeypatch.delenv(v, raising=False)
     cases = [((512, 4, 1, 0), (1, False)), ((1024, 5, 4, 0), (1, False)), ((2048, 6, 1, 0), (2, True)), ((2048, 0, 1, 0), (2, False)),
-             ((2048, 6, 8, 0), (2, True)), ((2048, 6, 2, 0), (1, False)), ((2048, 0, 8, 0), (2, True)), ((2048, 6, 8, mp.FLAG_LINEAR), (1, True)), ((2048, 6, 1, mp.FLAG_NO_AUTOTUNE | mp.FLAG_NO_GRAPH), (1, False)),
+             ((2048, 6, 8, 0), (2, True)), ((2048, 6, 2, 0), (1, False)), ((2048, 0, 8, 0), (2, True)), ((2048, 6, 8, mp.FLAG_LINEAR), (1, True)), ((2048, 6, 1, mp.FLAG_ONE_SHOT), (1, False)), ((2048, 6, 1, mp.FLAG_NO_AUTOTUNE | mp.FLAG_NO_GRAPH), (2, False)),
              ((4096, 8, 1, mp.FLAG_CLAHE), (2, True))]
     for (n, levels, batch, flags), want in cases:
         p = _proc(n, levels, batch=batch, flags=flags)
@@ -875,3 +875,26 @@ def test_create_ex_refuses_unusable_tunables():
     assert not p.init(512, levels=4, tunables=mp.default_tunables(nr_low_cnr=9.0))          # == nr_high_cnr: the slope divides by zero
     assert "nr_high_cnr == nr_low_cnr" in mp.last_error()
     assert not p.init(512, levels=4, tunables=mp.default_tunables(low_contrast_max_enhancement=float("nan")))
+
+
+@pytest.mark.parametrize("one_launch", ["1", "0"])
+def test_exact_zeros_recount_with_two_column_blocks(ob, one_launch, monkeypatch):
+    """The literal recount of a collimated image where k_grad_recount_curve's grid is two column blocks wide (sides above 4096: 16
+    wavefronts of 256 columns side by side cover 4096): columns beyond 4096 hold zeros AND data, three executes in a row (the last-ticket
+    hand-off re-arms), both launch forms. 8192^2 is a BASELINE configuration; 4104^2 has the same grid shape at a fifth of the oracle's time."""
+    monkeypatch.setenv("MUSICA_GRAD_ONE_LAUNCH", one_launch)
+    n, levels = 4104, 4
+    a = phantom(n, 71)
+    a[:150, :] = 0
+    a[:, :170] = 0
+    a[-260:, :] = 0
+    a[:, -190:] = 0          # zeros inside the second column block (columns 4096 .. 4103 are all zero; 3914 .. 4095 too)
+    a[1000:1100, 4000:4104] = 0
+    o = ob.Oracle(n, levels, ob.ORDER_FAST).execute(a)
+    assert (o.image(ob.IMG_EXPAND, 0) == 0.0).sum() > 1000
+    p = _proc(n, levels)
+    assert p.fuses_gradhist()
+    for rep in range(3):
+        assert p.execute(a), mp.last_error()
+        _compare_all(p, o, ob, tag="two column blocks, execute %d: " % rep)
+    p.cleanup()
