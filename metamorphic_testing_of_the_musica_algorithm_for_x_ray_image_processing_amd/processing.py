@@ -464,7 +464,7 @@ class MusicaProcessing:
 
     def dispatch_text(self):
         st, g = self.dispatch()
-        return "%s, %s" % ({1: "one stream", 2: "two streams (analysis beside the reduce tail)", 3: "three streams"}[st],
+        return "%s, %s" % ({1: "one stream", 2: "two streams (analysis beside the reduce tail)"}[st],
                            "hipGraph replay" if g else "eager launches")
 
     def fuses_gradhist(self):
