@@ -78,6 +78,17 @@ int main(int argc, char** argv) {
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     printf("pixels per launch: %zu\n", px);
+    if (argc > 3 && atoi(argv[3]) == 2) {   // a read-only launch behind a write-heavy one, alternating (rocprofv3 --kernel-trace gives the per-kernel durations):
+        const size_t groups = px / 8;      // does the 67 MB read slow down while the previous launch's stores drain?
+        for (int i = 0; i < 60; i++) {
+            const Set& q = s[i % NB];
+            const Set& r = s[(i + NB / 2) % NB];
+            hipLaunchKernelGGL((k_mix<2 | 16, 0>), dim3(16384), dim3(256), 0, st, q.u, q.a, q.b, q.c, q.o, q.oc, sink, groups);   // read 134 MB, write 134 MB
+            hipLaunchKernelGGL((k_mix<1, 0>), dim3(4096), dim3(256), 0, st, r.u, r.a, r.b, r.c, r.o, r.oc, sink, groups);          // read 67 MB
+        }
+        CK(hipStreamSynchronize(st));
+        return 0;
+    }
     if (argc > 3) {   // reads only
         run<1, 0>("read u16 only (r2)", s, NB, sink, px, st, a, b, 2.0);
         run<2, 0>("read f32 only (r4)", s, NB, sink, px, st, a, b, 4.0);

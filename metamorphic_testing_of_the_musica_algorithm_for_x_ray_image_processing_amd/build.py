@@ -3,9 +3,10 @@
     python -m metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd.build
 
 -ffp-contract=off keeps every f32 multiply and add separately rounded (the parity contract with
-oracle/musica_oracle.c); IEEE division and sqrt are hipcc's default for HIP. -fno-slp-vectorize: on gfx950 a packed
-f32 multiply or add costs what two plain ones cost, and the pairs the SLP vectoriser builds cost v_mov on top (the
-kernels write the one packed form that pays, v_pk_fma_f32, themselves; profiles/r04_rb0_experiments.txt).
+oracle/musica_oracle.c); IEEE division and sqrt are hipcc's default for HIP. -fno-slp-vectorize for kernels_analysis.hip
+only (NO_SLP below): on gfx950 a packed f32 multiply or add costs what two plain ones cost and the pairs the SLP vectoriser
+builds cost v_mov on top (profiles/r04_rb0_experiments.txt) — the sdev + noise-histogram march gains 5 % at 8 x 2048^2
+(59.4 -> 56.6 us); the pyramid kernels are equal at 2048^2 and 5 % slower at 8192^2 without SLP, so they keep it.
 """
 import os
 import subprocess
@@ -18,7 +19,8 @@ CLI = os.path.join(HERE, "musica-standalone")
 HIP_SOURCES = ["kernels_pyramid.hip", "kernels_analysis.hip", "kernels_gradation.hip", "kernels_clahe.hip", "kernels_bench.hip", "musica_ctx.hip"]
 CPP_SOURCES = ["musica_io.cpp"]
 HEADERS = ["musica_device.h", "kernels_common.h", "exact_math.h", "sdev_parts.h", "grad_parts.h", "launchers.h", os.path.join("..", "..", "include", "musica.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+NO_SLP = {"kernels_analysis.hip"}
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
 def _hipcc():
@@ -47,7 +49,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
-            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", obj]
+            cmd = [hipcc] + FLAGS + (["-fno-slp-vectorize"] if src in NO_SLP else []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -738,8 +738,8 @@ void launch_minmax(hipStream_t st, const uint16_t* px, int N, uint32_t* minmax, 
     // with a batch behind them. Measured with rocprofv3 (profiles/r03_minmax_shapes.txt, r04_minmax.txt): 8 x 2048^2 21 - 22 us, one
     // 2048^2 image 5.8 - 7.3 us, one 8192^2 image 39 - 40 us whatever the shape (256 ... 1024 threads, 1 ... 8 loads per lane, 64 ... 2048
     // blocks per image, chunks contiguous or a grid-width apart, images skewed against each other). Round 3 blamed the previous step's
-    // gradation apply (268 MB of stores still draining); round 4 refuted that: first in its stream on a drained, idle device the launch
-    // takes 23.5 us, and its streaming loop alone (no clears, no ticket tail, the grid of a plain copy kernel) 19.5 us.
+    // gradation apply (268 MB of stores still draining); round 4: a plain read behind a write-heavy launch does take 15.6 us instead of 10.5,
+    // and this launch's streaming loop alone (no clears, no ticket tail, the grid of a plain copy kernel) 19.5 us inside the pipeline.
     const size_t per_block = (size_t)kMinMaxThreads * kMinMaxLoads;
     size_t blocks = (count / 8 + per_block - 1) / per_block;
     const size_t maxb = batch >= 4 ? 128 : 256;

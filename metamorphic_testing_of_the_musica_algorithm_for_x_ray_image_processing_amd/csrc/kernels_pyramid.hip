@@ -400,38 +400,36 @@ __device__ __forceinline__ void lowpass_pair(const CRow& a, const CRow& b, const
 // (four raw halo pixels per row instead of two / one). Every value is produced by the expressions of reduce_row() and
 // lowpass_pair(), so both outputs are bit-identical to the two-kernel path (tested against the oracle and against it).
 // ======================================================================================
-// The strip's halo columns — c0-4 .. c0-1 left of it (lane 0 needs them) and c0+512 .. c0+514 right of it (lane 63) — are spread
-// over the quad of lanes they belong to, ONE column per lane: lane q of the first quad carries column c0-4+q, lane 60+q of the last
-// quad column c0+512+q (round 4; until then every lane carried four halo pixels through normalisation and the vertical chain, a
-// third of both, for two lanes' benefit). The vertical chain runs on that one value; four quad-broadcast DPP moves then hand every
-// lane of a quad all four sums, so lane 0 / 63 evaluate the same expressions on the same values as before.
+// (Round 4 measured the halo columns spread over the lanes of the first and last quad, one column per lane, with quad-broadcast DPP moves:
+// 540 -> 503 vector instructions per trip and the same 49 - 53 us at 8 x 2048^2 — but 96 - 115 us instead of 89 - 91 us at 8192^2, eight 2-byte
+// halo requests per row instead of two 8-byte ones; the round-3 form below stays. profiles/r04_rb0_experiments.txt)
 struct FRow {
     float v[8];   // normalized pixels c .. c+7
-    float h;      // lanes 0..3: column c0-4+lane (strips with a left neighbour); lanes 60..63: column c0+512+(lane-60) (strips with a right neighbour); 0 elsewhere
+    float h[4];   // c-4 .. c-1 on lane 0, c+8 .. c+11 on lane 63 (strips with a neighbour on that side; 0 elsewhere)
 };
 struct RawF {
     float4 m;     // 8 raw uint16 (bit pattern)
-    uint32_t h;   // the lane's raw halo pixel
+    float2 h;     // 4 raw halo pixels
 };
-__device__ __forceinline__ float quad_bcast0(float v) { const int s = __builtin_bit_cast(int, v); return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(s, s, 0x00, 0xF, 0xF, true)); }
-__device__ __forceinline__ float quad_bcast1(float v) { const int s = __builtin_bit_cast(int, v); return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(s, s, 0x55, 0xF, 0xF, true)); }
-__device__ __forceinline__ float quad_bcast2(float v) { const int s = __builtin_bit_cast(int, v); return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(s, s, 0xAA, 0xF, 0xF, true)); }
-__device__ __forceinline__ float quad_bcast3(float v) { const int s = __builtin_bit_cast(int, v); return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(s, s, 0xFF, 0xF, 0xF, true)); }
 __device__ __forceinline__ void load_raw_f(RawF& r, const Buf& b, uint32_t row_off, uint32_t off, uint32_t off_h) {
     r.m = bload4(b, off + row_off);
-    r.h = bload_u16(b, off_h + row_off);
+    r.h = bload2(b, off_h + row_off);
 }
 __device__ __forceinline__ void convert_f(FRow& r, const RawF& w, const NormK& nk) {
     norm8(r.v, w.m, nk);
-    r.h = norm_px(w.h, nk);
+    const uint32_t a = __float_as_uint(w.h.x), b = __float_as_uint(w.h.y);
+    r.h[0] = norm_px(a & 0xFFFFu, nk);
+    r.h[1] = norm_px(a >> 16, nk);
+    r.h[2] = norm_px(b & 0xFFFFu, nk);
+    r.h[3] = norm_px(b >> 16, nk);
 }
 // One coarse row (the lane's 4 columns + the halo column of an edge lane) from its five fine rows: reduce_row()'s arithmetic.
 __device__ __forceinline__ void coarse_row(CRow& cr, const FRow& r0, const FRow& r1, const FRow& r2, const FRow& r3, const FRow& r4, const LaneCfg& g) {
     float v[8], vh[4];
 #pragma unroll
     for (int j = 0; j < 8; j++) v[j] = chain5(r0.v[j], r1.v[j], r2.v[j], r3.v[j], r4.v[j]);
-    const float vq = chain5(r0.h, r1.h, r2.h, r3.h, r4.h);
-    vh[0] = quad_bcast0(vq); vh[1] = quad_bcast1(vq); vh[2] = quad_bcast2(vq); vh[3] = quad_bcast3(vq);   // lane 0: columns c-4 .. c-1; lane 63: c+8 .. c+11
+#pragma unroll
+    for (int j = 0; j < 4; j++) vh[j] = chain5(r0.h[j], r1.h[j], r2.h[j], r3.h[j], r4.h[j]);
     float vl6 = from_left_lane(v[6]);
     float vl7 = from_left_lane(v[7]);
     float vr0 = from_right_lane(v[0]);
@@ -478,7 +476,8 @@ __device__ __forceinline__ uint32_t le090_bits(const FRow& fe, const FRow& fo) {
 
 __device__ __forceinline__ void load_f(FRow& r, const Buf& b, uint32_t row_off, uint32_t off, uint32_t off_h) {
     load8(r.v, b, off + row_off);
-    r.h = bload1(b, off_h + row_off);
+    const float4 h = bload4(b, off_h + row_off);
+    r.h[0] = h.x; r.h[1] = h.y; r.h[2] = h.z; r.h[3] = h.w;
 }
 
 // rows_per_wave counts coarse rows. grid: x = strips, y = ceil(segments / 4), z = batch.
@@ -516,10 +515,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __
     // own pixels and four halo pixels: c-4 .. c-1 (lane 0 of a strip that is not the first) or c+8 .. c+11 (lane 63 with more image to its right)
     const uint32_t px_bytes = U16 ? 2u : 4u;
     const uint32_t foff = g.off == kOob ? kOob : (uint32_t)g.c * px_bytes;
-    // the lane's halo column: c0-4+lane on lanes 0..3 of a strip that is not the first, c0+512+(lane-60) on lanes 60..63 of a strip with more image to its right
-    const int c0s = tile.strip * kStripCols;
-    const uint32_t foff_h = (lane < 4 && c0s > 0 && c0s < S) ? (uint32_t)(c0s - 4 + lane) * px_bytes
-                          : (lane >= 60 && c0s + kStripCols < S) ? (uint32_t)(c0s + kStripCols + lane - 60) * px_bytes : kOob;
+    const uint32_t foff_h = g.off_l != kOob ? (uint32_t)(g.c - 4) * px_bytes : (g.off_r != kOob ? (uint32_t)(g.c + 8) * px_bytes : kOob);
     const int hi = S - 1;
     const uint32_t frb = U16 ? (uint32_t)S * 2u : (uint32_t)pitch * 4u, rb = (uint32_t)pitch * 4u, crb = (uint32_t)cpitch * 4u;
     const int ks = max(k0 - 1, 0), ke = min(k1, Sc - 1);   // coarse rows this wavefront computes (the first / last only feed its band rows)
