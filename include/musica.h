@@ -206,8 +206,8 @@ int musica_fuses_reduce_band(const musica_ctx* ctx);
 uint32_t musica_get_level_size(const musica_ctx* ctx, uint32_t level);
 /* How this context dispatches a step (chosen by musica_create from the batch, the image side, the depth of the pyramid and the
  * flags): *streams = 1 (the reference's one in-order queue), 2 (the analysis launches on a second stream
- * beside the reduce tail: the default for everything but small steps) or 3 (the three-stream script, MUSICA_DAG=1); *graph = 1 when steps replay a captured hipGraph, 0 for
- * eager launches. Either pointer may be NULL. Returns 1, 0 for a NULL context. */
+ * beside the reduce tail: the default for everything but small steps; MUSICA_STREAMS=1|2 overrides); *graph = 1 when steps replay a
+ * captured hipGraph, 0 for eager launches. Either pointer may be NULL. Returns 1, 0 for a NULL context. */
 int musica_get_dispatch(const musica_ctx* ctx, int* streams, int* graph);
 
 /* ---- the hot path ---------------------------------------------------- */

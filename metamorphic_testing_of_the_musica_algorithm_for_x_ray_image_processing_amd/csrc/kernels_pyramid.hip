@@ -345,8 +345,9 @@ struct CRow {
 __device__ __forceinline__ void load_crow(CRow& r, const Buf& b, uint32_t row_off, const LaneCfg& g) {
     const float4 a = bload4(b, g.coff + row_off);
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.hl = bload1(b, g.coff_l + row_off);
-    r.hr = bload1(b, g.coff_r + row_off);
+    // one halo column per edge lane: lane 0 reads j0-1, lane 63 reads j0+4 (every other lane carries kOob on both) — one load, one register;
+    // hl and hr hold the same value and the two chains the callers build on them are one
+    r.hl = r.hr = bload1(b, (g.lane0 ? g.coff_l : g.coff_r) + row_off);
 }
 
 // Horizontal pass for the 8 fine columns of a lane from its 4 coarse V values + neighbours; returns 4 * H.
@@ -698,11 +699,11 @@ __device__ __forceinline__ float curve_eval_lut(const CurveLds& t, const LutLds&
 // kernel (k_grad_hist) then recounts that image into a second histogram and k_grad_curve takes that one. The relevance
 // weight uint(relevant * 100) is the one k_grad_hist computes: one cnr classification per lane and row pair (the cnr scale
 // is 8 here, so a lane's 8 columns and both rows of a pair sit under one cnr texel), `normalized <= 0.9` on the raw pixel.
-// MASK: `normalized <= 0.9` comes as the bit image k_reduce_band<true> wrote (2 bytes per lane and row pair) instead of raw pixels
-// against thr090 (32 bytes).
+// `normalized <= 0.9` comes as the bit image k_reduce_band<true> wrote (2 bytes per lane and row pair; the raw-pixel form, 32 bytes
+// against the threshold thr090, left in round 4).
 // CNR48: the cnr scale is 4 or 8 (levels 1 and 0 of every image side that is a multiple of 8): columns c..c+3 and c+4..c+7 of a
 // lane each sit under one cnr texel. Wave-uniform like LUTOK and chosen the same way (the other form divides per texel).
-// CH (with GH + MASK, CLAHE contexts): the launch also accumulates clahe_histogram.comp:13-45 — hist[tx][ty][bin] += 1 where
+// CH (with GH, CLAHE contexts): the launch also accumulates clahe_histogram.comp:13-45 — hist[tx][ty][bin] += 1 where
 // relevant == 1.0 — of the texels it reconstructs (k_clahe_hist<true> re-read the whole reconstruction and the raw pixels for it:
 // 36 us for one 4096^2 image). relevant == 1.0 is relevant_of()'s value spelled out: inside the border and either the ramp
 // value ((r*r)*(r*r))*r itself 1.0 or cnr in [6, 256] with `normalized <= 0.9`. A workgroup's 512 columns and its rows touch at
@@ -712,8 +713,6 @@ template <int GAIN, bool NR, bool GH, bool LUTOK, bool CNR48, bool CH = false>
 __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds& tab, const LutLds& lut, uint32_t* lh, int img, uint32_t* lc = nullptr,
                                              uint32_t tx0 = 0u, uint32_t ty0 = 0u) {
     constexpr int kGhCopies = 4, kGhStride = MUSICA_GRAD_BINS + 8;
-    constexpr int T = 1;          // coarse rows per trip (two per trip lost everywhere it was measured and left in round 4)
-    constexpr bool MASK = true;   // `normalized <= 0.9` always comes as k_reduce_band<true>'s bit image (the raw-pixel form left in round 4)
     // slope of noise_reduction.comp:28, the same value for every texel
     const float nr_m = (a.highFactor - a.lowFactor) / (a.highCnr - a.lowCnr);
     const int lane = threadIdx.x & 63;
@@ -729,12 +728,11 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
     const Buf sb = make_buf((GAIN != GAIN_CONST ? a.sdev : a.band) + (size_t)img * a.plane, a.plane * 4);
     const Buf ob = make_buf(a.recon + (size_t)img * a.plane, a.plane * 4);
     const Buf pb = make_buf(a.prev + (size_t)img * a.cplane, a.cplane * 4);
-    const Buf wb = !GH ? bb : MASK ? make_buf(a.le090 + (size_t)img * a.Sc * (S / 8), (size_t)a.Sc * (S / 8) * 2) : make_buf(a.raw + (size_t)img * S * S, (size_t)S * S * 2);
+    const Buf wb = !GH ? bb : make_buf(a.le090 + (size_t)img * a.Sc * (S / 8), (size_t)a.Sc * (S / 8) * 2);   // `normalized <= 0.9` as k_reduce_band<true>'s bit image
     const float* cnr = NR ? a.cnr + (size_t)img * a.cnrPlane : nullptr;
     const LaneCfg g = make_cfg(tile.strip, lane, S);
     const uint32_t rb = (uint32_t)a.pitch * 4u, crb = (uint32_t)a.cpitch * 4u;
     const uint32_t moff = g.off == kOob ? kOob : (uint32_t)g.c >> 2, mrb = (uint32_t)S >> 2;
-    const uint32_t urb = (uint32_t)S * 2u, uoff = g.off == kOob ? kOob : g.off >> 1;
     // noise reduction: the 8 columns of a lane share ceil(8 / scale) cnr texels per row
     const int cxs[2] = {g.active ? g.c / cnrScale : 0, g.active ? (g.c + 4) / cnrScale : 0};
     // gradation histogram: img_relevant.comp:46-49 in uint arithmetic (wraps for N < 100 like the shader)
@@ -745,7 +743,6 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
         for (int j = 0; j < 8; j++)
             if (g.active && (uint32_t)(g.c + j) > border && (uint32_t)(g.c + j) < lim) colin |= 1u << j;
     }
-    const int thr = GH && !MASK ? a.thr090[img] : 0;
     uint32_t* lhc = lh + (GH ? (lane & (kGhCopies - 1)) * kGhStride : 0);
     // CLAHE tile column of each of the lane's 8 columns, relative to the workgroup's first one (clahe_histogram.comp:34)
     const float fS = (float)S;
@@ -756,109 +753,124 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
     }
     uint32_t* lcc = CH ? lc + (lane & (kChCopies - 1)) * (kChSlots * MUSICA_CLAHE_BINS) : nullptr;
 
-    CRow cw[T + 2];
-    load_crow(cw[0], pb, (uint32_t)coarse_of_fine(2 * k0 - 2, S) * crb, g);
-    load_crow(cw[1], pb, (uint32_t)k0 * crb, g);
-    for (int k = k0; k < k1; k += T) {
-        float be[T][8], bo[T][8], se[T][8], so[T][8];
-        float4 we[T], wo[T];   // raw uint16 rows (GH)
-        uint32_t le[T];        // or their `<= 0.9` bits (GH, MASK)
+    // One row of a pair once its operands are in registers: contrast gain, noise reduction, addition, store, histograms.
+    auto row_phase = [&](const int ph, float* b, const float* sd, const float* low, const float* f, const uint32_t le_t,
+                         const int kk, const uint32_t w_cnr, const uint32_t w_dark_or_ramp, const bool one_ramp, const bool one_dark) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < T; t++) {
-            const int ka = min(k + t, k1 - 1);
-            load_crow(cw[t + 2], pb, (uint32_t)coarse_of_fine(2 * ka + 2, S) * crb, g);
-            load8(be[t], bb, g.off + (uint32_t)(2 * ka) * rb);
-            load8(bo[t], bb, g.off + (uint32_t)(2 * ka + 1) * rb);
-            if (GAIN != GAIN_CONST) {
-                load8(se[t], sb, g.off + (uint32_t)(2 * ka) * rb);
-                load8(so[t], sb, g.off + (uint32_t)(2 * ka + 1) * rb);
-            }
-            if (GH && MASK) le[t] = bload_u16(wb, moff + (uint32_t)ka * mrb);
-            else if (GH) {
-                we[t] = bload4(wb, uoff + (uint32_t)(2 * ka) * urb);
-                wo[t] = bload4(wb, uoff + (uint32_t)(2 * ka + 1) * urb);
-            }
+        for (int j = 0; j < 8; j++) {
+            // contrast_curve_apply.comp:61
+            float p = b[j] * (GAIN == GAIN_CURVE ? curve_eval_lut<LUTOK>(tab, lut, sd[j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? sd[j] : 0.0f, a.high, tab));
+            if (NR) p = p * f[j];   // noise_reduction.comp:57
+            b[j] = low[j] + p;      // img_addition.comp:15
         }
+        store8(ob, g.off + (uint32_t)(2 * kk + ph) * rb, b);
+        if (GH) {
+            const uint32_t dark = le_t >> (8 * ph);
+            const uint32_t y = (uint32_t)(2 * kk + ph);
+            const uint32_t m = (y > border && y < lim) ? colin : 0u;   // inside-the-border bits of the lane's 8 columns in this row
+            const uint32_t chy = CH ? min(f2u((float)y / fS * (float)MUSICA_CLAHE_TILES) - ty0, 1u) : 0u;   // clahe_histogram.comp:35 (wave-uniform)
 #pragma unroll
-        for (int t = 0; t < T; t++) {
-            if (k + t < k1) {  // wave-uniform
-                const int kk = k + t;
-                float lowE[8], lowO[8];
-                lowpass_pair(cw[t], cw[t + 1], cw[t + 2], g, lowE, lowO);
-                float fe[8], fo[8];  // noise-reduction factors of the two rows
-                float cnr_pair = 0.0f;   // cnr * 256 of the texel above this lane's row pair (GH: scale 8)
-                if (NR) {
-                    const size_t re = (size_t)((2 * kk) / cnrScale) * a.cnrPitch, ro = (size_t)((2 * kk + 1) / cnrScale) * a.cnrPitch;
-                    if (CNR48) {  // columns c..c+3 and c+4..c+7 each sit inside one cnr texel (c % 8 == 0)
-                        cnr_pair = cnr[re + cxs[0]] * kMaxCnrValue;
-                        const float e0 = nr_factor_m(cnr_pair, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
-                        const float e1 = nr_factor_m(cnr[re + cxs[1]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
-                        const float o0 = nr_factor_m(cnr[ro + cxs[0]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
-                        const float o1 = nr_factor_m(cnr[ro + cxs[1]] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
-#pragma unroll
-                        for (int j = 0; j < 8; j++) { fe[j] = j < 4 ? e0 : e1; fo[j] = j < 4 ? o0 : o1; }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            const int cx = g.active ? (g.c + j) / cnrScale : 0;                 // noise_reduction.comp:39-45
-                            fe[j] = nr_factor_m(cnr[re + cx] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
-                            fo[j] = nr_factor_m(cnr[ro + cx] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
-                        }
-                    }
-                }
-                // img_relevant.comp:44-63 for the cnr texel above the row pair (rows 2kk, 2kk+1 and columns c..c+7 share it)
-                const CnrClass kc = classify_cnr(cnr_pair);
-                const uint32_t w_cnr = kc.ramp ? kc.w_ramp : 0u, w_dark_or_ramp = kc.ramp ? kc.w_ramp : (kc.high ? 100u : 0u);   // bright / dark pixel under this texel
-                // relevant == 1.0 (CH): the ramp value itself, else 1.0 for a dark pixel under a high-cnr texel (relevant_of)
-                const float r6 = cnr_pair / 6.0f;
-                const bool one_ramp = CH && kc.ramp && (((r6 * r6) * (r6 * r6)) * r6 == 1.0f);
-                const bool one_dark = CH && !kc.ramp && kc.high;
-#pragma unroll
-                for (int ph = 0; ph < 2; ph++) {   // even row, then odd row: each is stored (and binned) before the next is touched
-                    float* b = ph ? bo[t] : be[t];
-                    const float* sd = ph ? so[t] : se[t];
-                    const float* low = ph ? lowO : lowE;
-                    const float* f = ph ? fo : fe;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        // contrast_curve_apply.comp:61
-                        float p = b[j] * (GAIN == GAIN_CURVE ? curve_eval_lut<LUTOK>(tab, lut, sd[j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? sd[j] : 0.0f, a.high, tab));
-                        if (NR) p = p * f[j];   // noise_reduction.comp:57
-                        b[j] = low[j] + p;      // img_addition.comp:15
-                    }
-                    store8(ob, g.off + (uint32_t)(2 * kk + ph) * rb, b);
-                    if (GH) {
-                        const float4 wr = MASK ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ph ? wo[t] : we[t];
-                        const uint32_t raw[4] = {__float_as_uint(wr.x), __float_as_uint(wr.y), __float_as_uint(wr.z), __float_as_uint(wr.w)};
-                        const uint32_t dark = MASK ? le[t] >> (8 * ph) : 0u;
-                        const uint32_t y = (uint32_t)(2 * kk + ph);
-                        const uint32_t m = (y > border && y < lim) ? colin : 0u;   // inside-the-border bits of the lane's 8 columns in this row
-                        const uint32_t chy = CH ? min(f2u((float)y / fS * (float)MUSICA_CLAHE_TILES) - ty0, 1u) : 0u;   // clahe_histogram.comp:35 (wave-uniform)
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            const float cur = b[j];
-                            const int px = (int)((j & 1) ? (raw[j >> 1] >> 16) : (raw[j >> 1] & 0xFFFFu));
-                            saw_zero = saw_zero || (cur == 0.0f);                        // gradation_histogram.comp:24
-                            // :26 int(cur * 1024) with "NaN never indexes" (oracle Q6) and "bins outside [0, 1024) are dropped" (Q1) folded into
-                            // one unsigned compare: max(NaN, -1) = -1 and every scaled <= -1 convert to a negative int, i.e. a huge unsigned;
-                            // (-1, 0) truncates to bin 0 like the shader's int(); everything out of range lands on the spare word 1024
-                            const uint32_t bin = min((uint32_t)(int)fminf(fmaxf(cur * (float)MUSICA_GRAD_BINS, -1.0f), 2048.0f), (uint32_t)MUSICA_GRAD_BINS);
-                            // :28-30 uint(relevant * 100): 0 outside the border; adding 0 leaves the histogram as it is
-                            const bool le090 = MASK ? ((dark >> j) & 1u) != 0u : px <= thr;
-                            const uint32_t w = ((m >> j) & 1u) * (le090 ? w_dark_or_ramp : w_cnr);
-                            atomicAdd(&lhc[bin], w);
-                            if (CH) {
-                                const float scaled = cur * (float)(MUSICA_CLAHE_BINS - 1) + 0.5f;                 // clahe_histogram.comp:20
-                                const bool inrange = scaled > -1.0f && scaled < (float)MUSICA_CLAHE_BINS;       // NaN never indexes (Q6)
-                                if (((m >> j) & 1u) && inrange && (one_ramp || (one_dark && le090)))
-                                    atomicAdd(&lcc[((((chx >> j) & 1u) * 2u + chy) * MUSICA_CLAHE_BINS) + (uint32_t)(int)scaled], 1u);   // :39-44
-                            }
-                        }
-                    }
+            for (int j = 0; j < 8; j++) {
+                const float cur = b[j];
+                saw_zero = saw_zero || (cur == 0.0f);                        // gradation_histogram.comp:24
+                // :26 int(cur * 1024) with "NaN never indexes" (oracle Q6) and "bins outside [0, 1024) are dropped" (Q1) folded into
+                // one unsigned compare: max(NaN, -1) = -1 and every scaled <= -1 convert to a negative int, i.e. a huge unsigned;
+                // (-1, 0) truncates to bin 0 like the shader's int(); everything out of range lands on the spare word 1024
+                const uint32_t bin = min((uint32_t)(int)fminf(fmaxf(cur * (float)MUSICA_GRAD_BINS, -1.0f), 2048.0f), (uint32_t)MUSICA_GRAD_BINS);
+                // :28-30 uint(relevant * 100): 0 outside the border; adding 0 leaves the histogram as it is
+                const bool le090 = ((dark >> j) & 1u) != 0u;
+                const uint32_t w = ((m >> j) & 1u) * (le090 ? w_dark_or_ramp : w_cnr);
+                atomicAdd(&lhc[bin], w);
+                if (CH) {
+                    const float scaled = cur * (float)(MUSICA_CLAHE_BINS - 1) + 0.5f;                 // clahe_histogram.comp:20
+                    const bool inrange = scaled > -1.0f && scaled < (float)MUSICA_CLAHE_BINS;       // NaN never indexes (Q6)
+                    if (((m >> j) & 1u) && inrange && (one_ramp || (one_dark && le090)))
+                        atomicAdd(&lcc[((((chx >> j) & 1u) * 2u + chy) * MUSICA_CLAHE_BINS) + (uint32_t)(int)scaled], 1u);   // :39-44
                 }
             }
         }
-        cw[0] = cw[T]; cw[1] = cw[T + 1];
+    };
+    // The march is a software pipeline (round 4): while a wavefront computes one row of a pair, the operands of its NEXT row are in
+    // flight — the odd row's band / sdev registers are requested before the even row is computed, the next trip's even row into the even
+    // row's registers as soon as that row is stored, the next trip's coarse row into the registers of the coarse row that has just left
+    // the window, the next trip's cnr texels where this trip's have been consumed. No register more than the form that requested a whole
+    // trip at its top and waited for the first of them at once would need: 128 registers, 4 wavefronts per SIMD, no scratch (114 before).
+    // A trip that does not exist (beyond k1) requests out of range: no traffic.
+    CRow c0, c1, cn;
+    load_crow(c0, pb, (uint32_t)coarse_of_fine(2 * k0 - 2, S) * crb, g);
+    load_crow(c1, pb, (uint32_t)k0 * crb, g);
+    load_crow(cn, pb, (uint32_t)coarse_of_fine(2 * k0 + 2, S) * crb, g);
+    float be[8], bo[8], se[8], so[8];
+    uint32_t le = 0u;   // the pair's `<= 0.9` bits (GH)
+    // cnr texels of a trip (CNR48: scale 4 or 8): the left / right half of the lane's columns; rows 2k and 2k + 1 sit under the same
+    // cnr row at an even scale ((2k) / s == (2k + 1) / s), so a pair needs two texels, not four
+    float cq[2] = {0.0f, 0.0f};
+    auto load_cnr4 = [&](const int kk) __attribute__((always_inline)) {
+        const size_t re = (size_t)((2 * kk) / cnrScale) * a.cnrPitch;
+        cq[0] = cnr[re + cxs[0]]; cq[1] = cnr[re + cxs[1]];
+    };
+    if (NR && CNR48) load_cnr4(k0);
+    load8(be, bb, g.off + (uint32_t)(2 * k0) * rb);
+    if (GAIN != GAIN_CONST) load8(se, sb, g.off + (uint32_t)(2 * k0) * rb);
+    if (GH) le = bload_u16(wb, moff + (uint32_t)k0 * mrb);
+    for (int k = k0; k < k1; k++) {
+        const bool more = k + 1 < k1;                     // wave-uniform
+        const int kn = k + 1;
+        const uint32_t goff_n = more ? g.off : kOob;      // next trip's rows: the lane's columns, or nothing
+        // the next pair's `<= 0.9` bits a whole trip ahead (2 bytes per lane): requested with the next even row they would make the
+        // bottom of the loop wait for that row (the rotation le = le_n is a register move of a loaded value)
+        uint32_t le_n = 0u;
+        if (GH) le_n = bload_u16(wb, (more ? moff : kOob) + (uint32_t)kn * mrb);
+        // the odd row of this trip: in flight while the even row is computed
+        load8(bo, bb, g.off + (uint32_t)(2 * k + 1) * rb);
+        if (GAIN != GAIN_CONST) load8(so, sb, g.off + (uint32_t)(2 * k + 1) * rb);
+        float lowE[8], lowO[8];
+        lowpass_pair(c0, c1, cn, g, lowE, lowO);
+        c0 = c1; c1 = cn;
+        {   // coarse row of the next trip (k + 2's neighbourhood), a whole trip ahead
+            const LaneCfg& gg = g;
+            const uint32_t row_off = (uint32_t)coarse_of_fine(2 * kn + 2, S) * crb;
+            const float4 q = bload4(pb, (more ? gg.coff : kOob) + row_off);
+            cn.v[0] = q.x; cn.v[1] = q.y; cn.v[2] = q.z; cn.v[3] = q.w;
+            cn.hl = cn.hr = bload1(pb, (more ? (gg.lane0 ? gg.coff_l : gg.coff_r) : kOob) + row_off);
+        }
+        float fe[8], fo[8];  // noise-reduction factors of the two rows
+        float cnr_pair = 0.0f;   // cnr * 256 of the texel above this lane's row pair (GH: scale 8)
+        if (NR) {
+            if (CNR48) {  // columns c..c+3 and c+4..c+7 each sit inside one cnr texel (c % 8 == 0)
+                cnr_pair = cq[0] * kMaxCnrValue;
+                const float e0 = nr_factor_m(cnr_pair, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
+                const float e1 = nr_factor_m(cq[1] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
+#pragma unroll
+                for (int j = 0; j < 8; j++) { fe[j] = j < 4 ? e0 : e1; fo[j] = fe[j]; }
+                load_cnr4(more ? kn : k);   // branch-free: the last trip asks for its own texels again
+            } else {
+                const size_t re = (size_t)((2 * k) / cnrScale) * a.cnrPitch, ro = (size_t)((2 * k + 1) / cnrScale) * a.cnrPitch;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int cx = g.active ? (g.c + j) / cnrScale : 0;                 // noise_reduction.comp:39-45
+                    fe[j] = nr_factor_m(cnr[re + cx] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
+                    fo[j] = nr_factor_m(cnr[ro + cx] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
+                }
+            }
+        }
+        // img_relevant.comp:44-63 for the cnr texel above the row pair (rows 2k, 2k+1 and columns c..c+7 share it)
+        const CnrClass kc = classify_cnr(cnr_pair);
+        const uint32_t w_cnr = kc.ramp ? kc.w_ramp : 0u, w_dark_or_ramp = kc.ramp ? kc.w_ramp : (kc.high ? 100u : 0u);   // bright / dark pixel under this texel
+        // relevant == 1.0 (CH): the ramp value itself, else 1.0 for a dark pixel under a high-cnr texel (relevant_of)
+        const float r6 = cnr_pair / 6.0f;
+        const bool one_ramp = CH && kc.ramp && (((r6 * r6) * (r6 * r6)) * r6 == 1.0f);
+        const bool one_dark = CH && !kc.ramp && kc.high;
+        // (Left alone, the machine scheduler moves the first instructions on the odd row's operands — the NaN-quieting v_max of the
+        // lookup — up into the even row's phase, and the wait for the odd row with them. __builtin_amdgcn_sched_barrier(0) in front of
+        // either phase keeps them apart, and costs more than it saves: 153 registers, i.e. 84 bytes of scratch at 4 wavefronts per SIMD
+        // (116 us) or 3 wavefronts per SIMD (85.9 us, the same as this form: 85.2 - 87.2 against 89.4 - 89.7 us before the pipeline).)
+        row_phase(0, be, se, lowE, fe, le, k, w_cnr, w_dark_or_ramp, one_ramp, one_dark);
+        // the even row of the next trip into the registers the even row has just left
+        load8(be, bb, goff_n + (uint32_t)(2 * kn) * rb);
+        if (GAIN != GAIN_CONST) load8(se, sb, goff_n + (uint32_t)(2 * kn) * rb);
+        row_phase(1, bo, so, lowO, fo, le, k, w_cnr, w_dark_or_ramp, one_ramp, one_dark);
+        le = le_n;
     }
     }
     return saw_zero;

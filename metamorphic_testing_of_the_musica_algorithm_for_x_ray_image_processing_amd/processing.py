@@ -457,7 +457,7 @@ class MusicaProcessing:
         return out
 
     def dispatch(self):
-        """(streams, graph): 1 / 2 / 3 streams and whether steps replay a captured hipGraph (musica_get_dispatch)."""
+        """(streams, graph): 1 / 2 streams and whether steps replay a captured hipGraph (musica_get_dispatch)."""
         st, g = C.c_int(0), C.c_int(0)
         self._lib.musica_get_dispatch(self._h, C.byref(st), C.byref(g))
         return st.value, bool(g.value)
