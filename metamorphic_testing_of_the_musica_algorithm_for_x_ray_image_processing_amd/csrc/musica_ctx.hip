@@ -158,6 +158,21 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// MUSICA_TIMING=1: where the host-side time of create / save goes, one line per phase on stderr (the drop-in CLI is one process per
+// image: its wall time is start-up, allocation and file I/O, not the pipeline)
+struct Tick {
+    bool on;
+    std::chrono::high_resolution_clock::time_point t;
+    const char* what;
+    explicit Tick(const char* w) : on(env_int("MUSICA_TIMING", 0) != 0), t(std::chrono::high_resolution_clock::now()), what(w) {}
+    void lap(const char* phase) {
+        if (!on) return;
+        const auto n = std::chrono::high_resolution_clock::now();
+        fprintf(stderr, "[musica timing] %s: %s %.2f ms\n", what, phase, std::chrono::duration<float, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 template <typename T>
 static bool dalloc(musica_ctx* c, T** out, size_t count) {
     void* p = nullptr;
@@ -395,6 +410,7 @@ static musica_ctx* create_impl(const musica_params* params, const musica_tunable
     const bool small_step = c->B == 1 ? N < 2048 : (size_t)c->B * N * N <= (size_t)3072 * 3072;
     c->dag = !lone ? 0 : (env_int("MUSICA_STREAMS", (small_step || one_shot) ? 1 : 2) >= 2 ? 2 : 0);
     c->use_graph = !(params->flags & MUSICA_FLAG_NO_GRAPH) && env_int("MUSICA_GRAPH", (lone && (small_step || (c->B == 1 && L >= 11))) ? 0 : 1) != 0;
+    Tick tick("create");
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     if (c->dag) {
         ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
@@ -416,6 +432,7 @@ static musica_ctx* create_impl(const musica_params* params, const musica_tunable
     c->grad_one_launch = env_int("MUSICA_GRAD_ONE_LAUNCH", 1) != 0;
     c->fuse_gh = env_int("MUSICA_FUSE_GH", 1) != 0 && c->fuse_u16 && (!(params->flags & MUSICA_FLAG_CLAHE) || c->clahe_raw) &&
                  cnr_scale(c->lv[0].S, c->lv[MUSICA_CNR_LEVEL].S) == 8;
+    tick.lap("streams + events");
     ok = ok && dalloc(c, &c->d_input, B * N * N);
     ok = ok && dalloc(c, &c->d_minmax, B * kMinMaxStride);
     ok = ok && dalloc(c, &c->d_mm_slots, B * kMinMaxSlots);
@@ -454,7 +471,9 @@ static musica_ctx* create_impl(const musica_params* params, const musica_tunable
         ok = ok && dalloc(c, &c->d_clahe_pts, B * tb);
         ok = ok && dalloc(c, &c->d_clahe_graded, B * c->lv[0].plane);
     }
+    tick.lap("device buffers");
     ok = ok && hipMemcpy(c->d_cparams, c->h_cparams, sizeof(musica_contrast_params) * L, hipMemcpyHostToDevice) == hipSuccess;
+    tick.lap("parameter upload");
     if (!ok) {
         fail("musica_create: device allocation failed (%s)", hipGetErrorString(hipGetLastError()));
         musica_destroy(c);
@@ -1334,14 +1353,17 @@ static const uint8_t* out_pixels_pinned(musica_ctx* c, uint32_t idx) {
     const uint32_t N = (uint32_t)c->N, margin = MUSICA_OUT_MARGIN;
     if (N <= 2 * margin) { fail("saveOutImage: image too small for the %u-pixel margin", margin); return nullptr; }
     const size_t nw = N - 2 * margin, bytes = nw * nw;
+    Tick tick("save");
     if (!c->h_out8) {   // keyed on the LAST resource of the block: a call that failed half-way is retried, never half-initialised
         if (!c->d_out8 && !dalloc(c, &c->d_out8, bytes)) { fail("saveOutImage: device allocation failed"); return nullptr; }
         if (hipHostMalloc((void**)&c->h_out8, bytes, hipHostMallocDefault) != hipSuccess) { c->h_out8 = nullptr; fail("saveOutImage: pinned allocation failed"); return nullptr; }
     }
+    tick.lap("device + pinned buffers");
     launch_out_pixels(c->stream, c->d_graded + (size_t)idx * c->lv[0].plane, c->lv[0], (int)margin, c->d_out8);
     hipError_t e = hipMemcpyAsync(c->h_out8, c->d_out8, bytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { fail("saveOutImage: read-back failed: %s", hipGetErrorString(e)); return nullptr; }
+    tick.lap("crop + quantise kernel, read-back");
     return c->h_out8;
 }
 
@@ -1364,7 +1386,9 @@ int musica_save_out_image(musica_ctx* c, uint32_t idx, const char* path) {
     const uint8_t* px = out_pixels_pinned(c, idx);
     if (!px) return 0;
     const uint32_t nw = (uint32_t)c->N - 2 * MUSICA_OUT_MARGIN;
+    Tick tick("save");
     if (!musica_write_bmp_gray(path, nw, nw, px)) return fail("failed to write out file");  // :2636-2642
+    tick.lap("bmp file");
     return 1;
     ABI_CATCH("musica_save_out_image")
 }
