@@ -564,7 +564,7 @@ def main():
                        "wall_ms_median": round(walls[mid], 1), "wall_ms_all": [round(w, 1) for w in walls],
                        "own_line_ms_of_the_median_run": dict(zip(["init", "exec", "save", "tot", "hip_startup", "create", "read", "cleanup"], lines[mid])) if len(lines) == len(walls) else None,
                        "note": "init = hip_startup (first HIP call) + create (device allocation, streams) + read (raw file); exec = H2D + pipeline incl. the first-launch "
-                               "code-object loads; save = device crop + quantise, 1 B/px D2H into pinned memory, 28 MB BMP write; cleanup = musica_destroy; "
+                               "code-object loads; save = page-locked file image (5 ms), the BMP's 24-bpp rows written by the device straight into it, one 28 MB write (MUSICA_TIMING=1 prints the phases); cleanup = musica_destroy; "
                                "wall - tot - cleanup = process start (dynamic loading of the HIP runtime) and exit. No autotune, no graph capture in one-shot use."}
         # CPU baseline: the oracle (a port — the reference has no CPU path), all host cores, bounded sample
         cpu = None

@@ -116,6 +116,7 @@ void launch_grad_curve(hipStream_t st, uint32_t* hist, musica_hist_max_point* gm
 void launch_grad_apply(hipStream_t st, const float* in, float* out, const LevelDesc& l0, const DevCurve* curves, int batch);
 // crop + quantise of saveOutImage for ONE image plane: out = (S - 2 margin)^2 bytes, dense
 void launch_out_pixels(hipStream_t st, const float* graded, const LevelDesc& l0, int margin, uint8_t* out);
+void launch_out_bmp24(hipStream_t st, const float* graded, const LevelDesc& l0, int margin, uint32_t* out);   // the BMP file's pixel array (24 bpp, bottom-up, padded rows)
 // kernels_bench.hip (measurement aid)
 void launch_copy41(hipStream_t st, const float* in, float* out, int side);
 // kernels_clahe.hip

@@ -4,6 +4,7 @@
 //   output: stbi_write_bmp(path, w, h, comp = 1, data) as called by saveOutImage
 //           (src/vk_processing.cpp:2636-2642): 24-bpp BI_RGB, gray replicated to B, G, R, rows stored
 //           bottom-up and padded to 4 bytes (dependencies/stb/stb_image_write.h:492-500, :451-476).
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -24,26 +25,26 @@ extern "C" int musica_read_raw(const char* path, uint32_t image_size, uint16_t* 
         return 0;
     }
     fseek(f, offset, SEEK_SET);
-    std::vector<uint8_t> buf((size_t)image_size * image_size * 2);
-    const size_t got = fread(buf.data(), 1, buf.size(), f);
-    fclose(f);
-    if (got != buf.size()) return 0;
     const size_t n = (size_t)image_size * image_size;
-    for (size_t i = 0; i < n; i++) dst[i] = (uint16_t)((buf[2 * i + 1] << 8) | buf[2 * i]);  // main.cpp:71-72
+    // main.cpp:71-72 composes pixel i as bytes[2i + 1] << 8 | bytes[2i]: the file is little-endian, and so is every host this library
+    // runs on (x86-64 beside an MI355X) — the bytes are read straight into the pixels; a big-endian build swaps them afterwards
+    const size_t got = fread(dst, 1, n * 2, f);
+    fclose(f);
+    if (got != n * 2) return 0;
+#if defined(__BYTE_ORDER__) && __BYTE_ORDER__ == __ORDER_BIG_ENDIAN__
+    for (size_t i = 0; i < n; i++) dst[i] = (uint16_t)((dst[i] << 8) | (dst[i] >> 8));
+#endif
     return 1;
 }
 
 static void le16(uint8_t* p, uint32_t v) { p[0] = (uint8_t)(v & 0xFF); p[1] = (uint8_t)((v >> 8) & 0xFF); }
 static void le32(uint8_t* p, uint32_t v) { le16(p, v & 0xFFFF); le16(p + 2, v >> 16); }
 
-extern "C" int musica_write_bmp_gray(const char* path, uint32_t w, uint32_t h, const uint8_t* data) {
-    if (!path || !data) return 0;
-    FILE* f = fopen(path, "wb");
-    if (!f) return 0;
-    setvbuf(f, nullptr, _IOFBF, 1 << 20);   // ~28 MB for a 3052^2 image: fewer, larger writes
+// The 54 header bytes of stbi_write_bmp(path, w, h, comp = 1, data); returns the padded row size.
+extern "C" uint32_t musica_bmp24_header(uint32_t w, uint32_t h, uint8_t hdr[54]) {
     const uint32_t pad = (uint32_t)(-(int32_t)(w * 3)) & 3u;
     const uint32_t row_bytes = w * 3 + pad;
-    uint8_t hdr[54] = {0};
+    for (int i = 0; i < 54; i++) hdr[i] = 0;
     hdr[0] = 'B'; hdr[1] = 'M';
     le32(hdr + 2, 14 + 40 + row_bytes * h);  // file size
     le32(hdr + 10, 14 + 40);                 // pixel data offset
@@ -52,6 +53,26 @@ extern "C" int musica_write_bmp_gray(const char* path, uint32_t w, uint32_t h, c
     le32(hdr + 22, h);
     le16(hdr + 26, 1);                       // planes
     le16(hdr + 28, 24);                      // bits per pixel; compression and the rest stay 0
+    return row_bytes;
+}
+// A whole file image (header + pixel array as the device wrote it) in one write.
+extern "C" int musica_write_file(const char* path, const uint8_t* bytes, size_t count) {
+    if (!path || !bytes) return 0;
+    FILE* f = fopen(path, "wb");
+    if (!f) return 0;
+    setvbuf(f, nullptr, _IONBF, 0);
+    bool ok = fwrite(bytes, 1, count, f) == count;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? 1 : 0;
+}
+
+extern "C" int musica_write_bmp_gray(const char* path, uint32_t w, uint32_t h, const uint8_t* data) {
+    if (!path || !data) return 0;
+    FILE* f = fopen(path, "wb");
+    if (!f) return 0;
+    setvbuf(f, nullptr, _IOFBF, 1 << 20);   // ~28 MB for a 3052^2 image: fewer, larger writes
+    uint8_t hdr[54];
+    const uint32_t row_bytes = musica_bmp24_header(w, h, hdr);
     bool ok = fwrite(hdr, 1, sizeof(hdr), f) == sizeof(hdr);
     std::vector<uint8_t> row(row_bytes, 0);
     for (int64_t j = (int64_t)h - 1; j >= 0 && ok; j--) {

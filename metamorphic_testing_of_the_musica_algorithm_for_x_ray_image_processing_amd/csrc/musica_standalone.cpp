@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -74,17 +75,17 @@ int main(int argc, char* argv[]) {
     ASSERT_MSG(ctx != nullptr, "failed to initialize vk processing");  // main.cpp:51 (message kept)
     const auto t0c = std::chrono::high_resolution_clock::now();
 
-    std::vector<uint16_t> pixels((size_t)imageSize * imageSize);
+    std::unique_ptr<uint16_t[]> pixels(new uint16_t[(size_t)imageSize * imageSize]);   // not zero-filled: the file fills it
     {
         FILE* f = fopen(rawFile.c_str(), "rb");
         ASSERT_MSG(f != nullptr, "failed to load file");  // main.cpp:55
         fclose(f);
     }
-    ASSERT_MSG(musica_read_raw(rawFile.c_str(), imageSize, pixels.data()),
+    ASSERT_MSG(musica_read_raw(rawFile.c_str(), imageSize, pixels.get()),
                "the image data don't match the actual image size");  // main.cpp:60
     const auto t1 = std::chrono::high_resolution_clock::now();
 
-    ASSERT_MSG(musica_execute(ctx, pixels.data()), "processing failed");  // main.cpp:77
+    ASSERT_MSG(musica_execute(ctx, pixels.get()), "processing failed");  // main.cpp:77
     const auto t2 = std::chrono::high_resolution_clock::now();
 
     ASSERT_MSG(musica_save_out_image(ctx, 0, outFile.c_str()), "failed to save out image");  // main.cpp:79
