@@ -1,0 +1,29 @@
+"""Same-box A/B of two library builds through bench.py's own timed region (three steps in flight): alternates the libraries, several
+processes each.   python devtools/bench_ab.py <workload> <rounds> NAME=path/to/lib.so NAME2=...      (paths relative to the repo root)"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+wl, rounds = sys.argv[1], int(sys.argv[2])
+libs = [a.split("=", 1) for a in sys.argv[3:]]
+res = {n: [] for n, _ in libs}
+one = {n: [] for n, _ in libs}
+code = ("import sys, os; sys.path.insert(0, %r); sys.argv = ['bench.py', '--workload', %r, '--cpu-seconds', '0', '--no-single-image', '--no-standalone', '--no-cli', '--no-pmc', '--no-kernel-events'];"
+        "from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd import processing as mp; mp.LIB_PATH = os.path.join(%r, os.environ['AB_LIB']);"
+        "import runpy; runpy.run_path(os.path.join(%r, 'bench.py'), run_name='__main__')") % (ROOT, wl, ROOT, ROOT)
+for r in range(rounds):
+    for name, path in libs:
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AB_LIB=path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if out.returncode != 0:
+            print(name, "failed:", out.stderr[-500:])
+            sys.exit(1)
+        line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        res[name].append(line["ms_per_step"])
+        if line.get("one_context"):
+            one[name].append(line["one_context"]["ms_per_step"])
+        print(r, name, line["ms_per_step"], line.get("one_context", {}).get("ms_per_step"), flush=True)
+for name, _ in libs:
+    v = sorted(res[name]); o = sorted(one[name])
+    print("%-8s ms_per_step median %.4f (min %.4f max %.4f)  one_context median %s" % (name, v[len(v) // 2], v[0], v[-1], ("%.4f" % o[len(o) // 2]) if o else "-"))
