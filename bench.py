@@ -62,12 +62,14 @@ COLD_BUFFERS = 8          # 8 x (64 MB in + 16 MB out) = 640 MB rotating footpri
 COLD_ITERS = 64
 
 
-def algorithmic_bytes(n, levels, batch, fused_u16=True, fused_gradhist=False, fused_rb=0, le090=False):
+def algorithmic_bytes(n, levels, batch, fused_u16=True, fused_gradhist=False, fused_rb=0, le090=False, fused_sdev=False):
     """Algorithmic HBM bytes per launch of each kernel family, f32 = 4 B, u16 = 2 B.
     fused_u16: the level-0 kernels read the raw uint16 pixels (2 B/px) instead of a stored normalized image (4 B/px);
     fused_rb: 1 = reduce + band of level 0 are one launch, 2 = of every level whose side is a multiple of 8 (then the
     `reduce_*` families carry the band image too and no `band_*` launch remains at those levels);
-    le090: the level-0 reduce + band launch also writes the 1 bit/px `normalized <= 0.9` image the expand launch reads."""
+    le090: the level-0 reduce + band launch also writes the 1 bit/px `normalized <= 0.9` image the expand launch reads;
+    fused_sdev: the expand launches of levels 0 .. 2 compute sdev from the band image themselves (musica_fuses_sdev): the sdev launches of
+    those levels only read (4 B/px) and the expand launches read no sdev image."""
     src = 2 if fused_u16 else 4
     s = [n]
     for _ in range(levels):
@@ -85,9 +87,9 @@ def algorithmic_bytes(n, levels, batch, fused_u16=True, fused_gradhist=False, fu
         "reduce_rest": sum((8 if i in rb_rest else 4) * p[i] + 4 * p[i + 1] for i in rest) * batch / max(1, len(rest)),
         "band_l0": ((src + 4) * p[0] + 4 * p[1]) * batch,                # read fine + coarse, write band
         "band_rest": sum(8 * p[i] + 4 * p[i + 1] for i in rest if i not in rb_rest) * batch / max(1, len(rest) - len(rb_rest)),
-        "sdev_hist": sum(8 * p[i] for i in range(4)) * batch / 4.0,      # read band, write sdev (hist in LDS)
-        "expand_l0": ((12 + raw_in_expand) * p[0] + 4 * p[1] + (mask if fused_gradhist else 0)) * batch,   # read band + sdev + coarse (+ raw or bits), write recon
-        "expand_rest": (sum(12 * p[i] + 4 * p[i + 1] for i in range(1, 4)) +
+        "sdev_hist": sum((4 if (fused_sdev and i < 3) else 8) * p[i] for i in range(4)) * batch / 4.0,      # read band, write sdev (hist in LDS)
+        "expand_l0": (((8 if fused_sdev else 12) + raw_in_expand) * p[0] + 4 * p[1] + (mask if fused_gradhist else 0)) * batch,   # read band (+ sdev) + coarse (+ raw or bits), write recon
+        "expand_rest": (sum((8 if (fused_sdev and i < 3) else 12) * p[i] + 4 * p[i + 1] for i in range(1, 4)) +
                         sum(8 * p[i] + 4 * p[i + 1] for i in range(4, levels))) * batch / max(1, len(rest)),
         "grad_hist": 0 if fused_gradhist else (4 + src) * p[0] * batch,  # read recon + normalized (or raw); fused: the launch only recounts images with exact zeros
         "grad_apply": 8 * p[0] * batch,                                  # read recon, write graded
@@ -253,6 +255,7 @@ def main():
     pipe.upload(px)                                                # inputs resident in HBM (one copy per context) before the timed region
     pipe.prime()                                                   # every context has captured its graph; the best set of hardware queues is kept
     queue_calibration = {str(k): round(v, 4) for k, v in pipe.calibration().items()} or None
+    sdev_in_expand = bool(pipe.context(0).fuses_sdev())              # the timed contexts compute sdev inside the expand launches of levels 0 .. 2 (no stored sdev images there)
     if depth == 1:
         proc = pipe.context(0)
     else:                                                          # the per-kernel passes and the other measurements: one context alone, default dispatch
@@ -380,7 +383,7 @@ def main():
         fused = n % 8 == 0
         rb_mode = 2 if proc.fuses_reduce_band() else 0
         le090 = bool(proc.fuses_gradhist() and rb_mode >= 1)
-        ab = algorithmic_bytes(n, levels, batch, fused, fused_gradhist=proc.fuses_gradhist(), fused_rb=rb_mode, le090=le090)
+        ab = algorithmic_bytes(n, levels, batch, fused, fused_gradhist=proc.fuses_gradhist(), fused_rb=rb_mode, le090=le090, fused_sdev=proc.fuses_sdev())
         kernels = {}
         total_kernel_us = 0.0
         for name, (us, cnt) in prof.items():
@@ -611,6 +614,7 @@ def main():
                         "and `cli` are the same pipeline in the reference's one-frame-at-a-time call shapes" % (args.steps, depth, batch),
             "config": {"workload": desc, "image_size": n, "levels": levels, "images_per_gpu_per_step": batch, "contexts_in_flight": depth, "untimed_rehearsals_of_the_job": rehearsals,
                        "queue_calibration_ms": queue_calibration,
+                       "sdev_in_expand_launches": sdev_in_expand,
                        "input": "seeded phantoms, %d-bit" % bits, "dispatch": "eager launches" if (kernel_events or os.environ.get("MUSICA_GRAPH", "1") == "0") else "hipGraph replay",
                        "kernel_events_in_timed_region": kernel_events, "sharding": "image k -> rank k mod N, no data-path collective",
                        "stats_gathered": int(st.shape[0]), "ranks_joined": world,

@@ -1,5 +1,5 @@
 """Same-box A/B of two library builds through bench.py's own timed region (three steps in flight): alternates the libraries, several
-processes each.   python devtools/bench_ab.py <workload> <rounds> NAME=path/to/lib.so NAME2=...      (paths relative to the repo root)"""
+processes each.   python devtools/bench_ab.py <workload> <rounds> NAME=path/to/lib.so[,ENV=VAL,...] NAME2=...      (paths relative to the repo root)"""
 import json
 import os
 import subprocess
@@ -7,7 +7,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 wl, rounds = sys.argv[1], int(sys.argv[2])
-libs = [a.split("=", 1) for a in sys.argv[3:]]
+libs, envs = [], {}
+for a in sys.argv[3:]:   # NAME=path[,ENV=VAL,...]
+    name, rest = a.split("=", 1)
+    parts = rest.split(",")
+    libs.append([name, parts[0]])
+    envs[name] = dict(kv.split("=", 1) for kv in parts[1:])
 res = {n: [] for n, _ in libs}
 one = {n: [] for n, _ in libs}
 code = ("import sys, os; sys.path.insert(0, %r); sys.argv = ['bench.py', '--workload', %r, '--cpu-seconds', '0', '--no-single-image', '--no-standalone', '--no-cli', '--no-pmc', '--no-kernel-events'];"
@@ -15,7 +20,7 @@ code = ("import sys, os; sys.path.insert(0, %r); sys.argv = ['bench.py', '--work
         "import runpy; runpy.run_path(os.path.join(%r, 'bench.py'), run_name='__main__')") % (ROOT, wl, ROOT, ROOT)
 for r in range(rounds):
     for name, path in libs:
-        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AB_LIB=path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AB_LIB=path, **envs[name]), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         if out.returncode != 0:
             print(name, "failed:", out.stderr[-500:])
             sys.exit(1)

@@ -8,8 +8,9 @@ OBJ=$PKG/build/var_$NAME
 mkdir -p $OBJ
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-unused-value -Wno-unused-result"
 pids=()
-for f in kernels_pyramid kernels_analysis kernels_gradation kernels_clahe kernels_bench musica_ctx; do
-    /opt/rocm/bin/hipcc $FLAGS $EXTRA -x hip -c $PKG/csrc/$f.hip -o $OBJ/$f.o &
+for f in kernels_pyramid kernels_expand_sd kernels_analysis kernels_gradation kernels_clahe kernels_bench musica_ctx; do
+    NOSLP=""; case $f in kernels_analysis|kernels_expand_sd) NOSLP="-fno-slp-vectorize";; esac   # as build.py's NO_SLP
+    /opt/rocm/bin/hipcc $FLAGS $NOSLP $EXTRA -x hip -c $PKG/csrc/$f.hip -o $OBJ/$f.o &
     pids+=($!)
 done
 /opt/rocm/bin/hipcc $FLAGS -c $PKG/csrc/musica_io.cpp -o $OBJ/musica_io.o &

@@ -203,6 +203,11 @@ int musica_fuses_gradation_histogram(const musica_ctx* ctx);
 /* 1 when level 0's smooth + downsample and band-pass image come out of one launch (k_reduce_band_u16; the `reduce_l0` profile
  * family then covers both and `band_l0` stays empty), else 0. */
 int musica_fuses_reduce_band(const musica_ctx* ctx);
+/* 1 when the expand launches of levels 0 .. 2 compute the 5 x 5 RMS of their band image themselves and the sdev + noise-histogram
+ * launches of those levels store no image (whole-step execution only: getters, dumps and the stage entry points produce the stored
+ * images on demand, bit-identical); chosen per workload by musica_create, MUSICA_SDEV_IN_EXPAND=0|1 overrides. bench.py prices
+ * the launches accordingly. */
+int musica_fuses_sdev(const musica_ctx* ctx);
 uint32_t musica_get_level_size(const musica_ctx* ctx, uint32_t level);
 /* How this context dispatches a step (chosen by musica_create from the batch, the image side, the depth of the pyramid and the
  * flags): *streams = 1 (the reference's one in-order queue), 2 (the analysis launches on a second stream

@@ -16,10 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmusica_hip.so")
 CLI = os.path.join(HERE, "musica-standalone")
-HIP_SOURCES = ["kernels_pyramid.hip", "kernels_analysis.hip", "kernels_gradation.hip", "kernels_clahe.hip", "kernels_bench.hip", "musica_ctx.hip"]
+HIP_SOURCES = ["kernels_pyramid.hip", "kernels_expand_sd.hip", "kernels_analysis.hip", "kernels_gradation.hip", "kernels_clahe.hip", "kernels_bench.hip", "musica_ctx.hip"]
 CPP_SOURCES = ["musica_io.cpp"]
 HEADERS = ["musica_device.h", "kernels_common.h", "exact_math.h", "sdev_parts.h", "grad_parts.h", "launchers.h", os.path.join("..", "..", "include", "musica.h")]
-NO_SLP = {"kernels_analysis.hip"}
+NO_SLP = {"kernels_analysis.hip", "kernels_expand_sd.hip"}   # kernels_expand_sd.hip: kernels_pyramid.hip's expand march again, for the launches that compute sdev in registers
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -48,7 +48,8 @@ def build(force=False, verbose=False):
         sp = os.path.join(CSRC, src)
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [sp] + headers):
+        deps = [sp] + headers + ([os.path.join(CSRC, "kernels_pyramid.hip")] if src == "kernels_expand_sd.hip" else [])
+        if force or _stale(obj, deps):
             cmd = [hipcc] + FLAGS + (["-fno-slp-vectorize"] if src in NO_SLP else []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))

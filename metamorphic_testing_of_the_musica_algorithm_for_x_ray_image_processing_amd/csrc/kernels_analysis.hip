@@ -261,8 +261,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __r
     __syncthreads();
     const int img = blockIdx.z;
     const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
-    sdev += (size_t)img * plane;
-    const Buf db = make_buf(sdev, plane * 4);
+    const bool store = sdev != nullptr;   // nullptr: histogram only (the level's expand launch computes sdev itself, k_expand_fast<.., SD>)
+    if (store) sdev += (size_t)img * plane;
+    const Buf db = make_buf(store ? sdev : band, store ? plane * 4 : 0);
     const int lane = threadIdx.x & 63;
     const Tile tile = xcd_tile(swz);
     const int seg = __builtin_amdgcn_readfirstlane((int)(tile.segblock * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
@@ -289,12 +290,14 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __r
             // rows past the image carry an out-of-range offset: no access. (Non-temporal loads for the rows no neighbouring segment reads,
             // the trick that took 7 % off the metric kernel, change nothing here: 8 x 2048^2 33.6 - 37.7 us either way, 8192^2 55 -> 62 us.)
             load_sraw(raw, bb, roff(y + 3), g);
-            sdev_row<HIST, A8>(w0, w1, w2, w3, w4, g, S, y, cov, sdev + (size_t)y * pitch, db, (uint32_t)y * rb, lh, alive, start);
+            sdev_row<HIST, A8>(w0, w1, w2, w3, w4, g, S, y, cov, store ? sdev + (size_t)y * pitch : nullptr, db, (uint32_t)y * rb, lh, alive, start, store);
             w0 = w1; w1 = w2; w2 = w3; w3 = w4;
         }
     }
-    __syncthreads();
-    hist_lds_flush(lh, hist + (size_t)img * hist_stride);
+    if (HIST) {
+        __syncthreads();
+        hist_lds_flush(lh, hist + (size_t)img * hist_stride);
+    }
 }
 
 // ---- K10 + K11, one 16-row histogram run per workgroup ------------------------------------------------------
@@ -318,7 +321,8 @@ __device__ __forceinline__ void sdev_run_block(const float* __restrict__ band, f
                                                unsigned long long (*nzw)[8]) {
     hist_lds_clear(lh);
     const Buf bb = make_buf(band, plane * 4);
-    const Buf db = make_buf(sdev, plane * 4);
+    const bool store = sdev != nullptr;   // nullptr: histogram only
+    const Buf db = make_buf(store ? sdev : band, store ? plane * 4 : 0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int y0 = tile.segblock * kHistArea + wave * kRunRowsPerWave;   // wave-uniform
@@ -343,7 +347,7 @@ __device__ __forceinline__ void sdev_run_block(const float* __restrict__ band, f
             if (r < nrows) {   // wave-uniform
                 float s[8];
                 sdev_values(w[r], w[r + 1], w[r + 2], w[r + 3], w[r + 4], g, s);
-                sdev_store<A8>(s, g, sdev + (size_t)(y0 + r) * pitch, db, (uint32_t)(y0 + r) * rb);
+                if (store) sdev_store<A8>(s, g, sdev + (size_t)(y0 + r) * pitch, db, (uint32_t)(y0 + r) * rb);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     bin[r][j] = musica_noise_bin(s[j]);      // 0 = break (noise_hist.comp:29, :33, :39)
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_run(const float* __
     __shared__ uint32_t lh[kHistLdsWords];
     __shared__ unsigned long long nzw[kWavesPerBlock][8];
     const size_t img = blockIdx.z;
-    sdev_run_block<A8>(band + img * plane, sdev + img * plane, S, pitch, plane, hist + img * hist_stride, cov, xcd_tile(swz), lh, nzw);
+    sdev_run_block<A8>(band + img * plane, sdev ? sdev + img * plane : nullptr, S, pitch, plane, hist + img * hist_stride, cov, xcd_tile(swz), lh, nzw);
 }
 
 // The runs of SEVERAL levels in one launch (levels whose launch of their own would be a few dozen workgroups: a context
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_runs(const SdevRunL
     tile.strip = local % l.strips;
     tile.segblock = local / l.strips;
     const size_t img = blockIdx.z;
-    sdev_run_block<A8>(l.band + img * l.plane, l.sdev + img * l.plane, l.S, l.pitch, l.plane, l.hist + img * hist_stride, cov, tile, lh, nzw);
+    sdev_run_block<A8>(l.band + img * l.plane, l.sdev ? l.sdev + img * l.plane : nullptr, l.S, l.pitch, l.plane, l.hist + img * hist_stride, cov, tile, lh, nzw);
 }
 
 // histogram only (kernel-level parity tests feed a foreign sdev image): same scan, no stencil.
@@ -793,6 +797,15 @@ void launch_sdev_hist_runs(hipStream_t st, int n, const float* const* band, floa
     const dim3 grid(first, 1, batch);
     if (a8) hipLaunchKernelGGL((k_sdev_hist_runs<true>), grid, dim3(kBlockThreads), 0, st, a, hist_stride, cov);
     else hipLaunchKernelGGL((k_sdev_hist_runs<false>), grid, dim3(kBlockThreads), 0, st, a, hist_stride, cov);
+}
+
+// sdev alone (no histogram): the stored image of a level whose hot path does not store it, for getters / dumps / the stage entry points
+void launch_sdev_only(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, int batch) {
+    const int strips = (l.S + kStripCols - 1) / kStripCols, rows = 16;
+    const int segs = (l.S + rows - 1) / rows;
+    const dim3 grid(strips, (segs + kWavesPerBlock - 1) / kWavesPerBlock, batch);
+    if ((l.S & 7) == 0) hipLaunchKernelGGL((k_sdev_hist_pf<false, true>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, (uint32_t*)nullptr, (size_t)0, 0, rows, xcd_swizzle_on());
+    else hipLaunchKernelGGL((k_sdev_hist_pf<false, false>), grid, dim3(kBlockThreads), 0, st, band, sdev, l.S, l.pitch, l.plane, (uint32_t*)nullptr, (size_t)0, 0, rows, xcd_swizzle_on());
 }
 
 void launch_sdev_literal(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, int batch) {

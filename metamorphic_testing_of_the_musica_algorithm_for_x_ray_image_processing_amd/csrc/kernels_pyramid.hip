@@ -22,7 +22,16 @@
 // Both forms evaluate exactly the oracle's MUSICA_ORDER_FAST arithmetic.
 #include <stdlib.h>
 #include "kernels_common.h"
+#include "sdev_parts.h"
 #include "launchers.h"
+
+// kernels_expand_sd.hip includes this file with MUSICA_PYRAMID_SD_ONLY defined: the device code of the expand march compiled a second time,
+// without the SLP vectoriser, for the launches that compute sdev in registers (k_expand_fast<.., SD>: 172 registers that way, 211 with the
+// pairs the vectoriser builds — 3 or 2 wavefronts per SIMD). Everything that is not a template — the generic kernels and every launcher —
+// exists once, in the translation unit without that macro.
+#ifndef MUSICA_PYRAMID_SD_ONLY
+#define MUSICA_PYRAMID_FULL 1
+#endif
 
 namespace musica {
 
@@ -307,6 +316,7 @@ __device__ __forceinline__ float reduce_generic_at(const float* __restrict__ in,
     }
     return chain5(v[0], v[1], v[2], v[3], v[4]);
 }
+#ifdef MUSICA_PYRAMID_FULL
 __global__ void k_reduce_generic(const float* __restrict__ in, float* __restrict__ out, int S, int pitch,
                                  size_t in_plane, int So, int opitch, size_t out_plane, int ref) {
     const int xo = blockIdx.x * blockDim.x + threadIdx.x;
@@ -316,6 +326,7 @@ __global__ void k_reduce_generic(const float* __restrict__ in, float* __restrict
     out += (size_t)blockIdx.z * out_plane;
     out[(size_t)yo * opitch + xo] = reduce_generic_at(in, pitch, S, xo, yo, ref);
 }
+#endif
 
 // ======================================================================================
 // Zero-inserted upsample + x4 smooth (K7 + K8) of a coarse image, shared by band and expand.
@@ -603,6 +614,7 @@ __device__ __forceinline__ float lowpass_generic(const float* __restrict__ coars
     return 4.0f * chain5(V[0], V[1], V[2], V[3], V[4]);
 }
 
+#ifdef MUSICA_PYRAMID_FULL
 __global__ void k_band_generic(const float* __restrict__ fine, const float* __restrict__ coarse, float* __restrict__ band,
                                int S, int pitch, size_t plane, int Sc, int cpitch, size_t cplane, int ref) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -625,6 +637,7 @@ __global__ void k_lowpass_generic(const float* __restrict__ coarse, float* __res
     coarse += (size_t)blockIdx.z * cplane;
     low[(size_t)y * pitch + x] = lowpass_generic(coarse, cpitch, Sc, S, x, y, ref);
 }
+#endif
 
 // ======================================================================================
 // K14 + K16 + K7 + K8 + K17: recon = lowpass(prev) + band * gain(sdev) [* nr(cnr)]
@@ -709,7 +722,39 @@ __device__ __forceinline__ float curve_eval_lut(const CurveLds& t, const LutLds&
 // value ((r*r)*(r*r))*r itself 1.0 or cnr in [6, 256] with `normalized <= 0.9`. A workgroup's 512 columns and its rows touch at
 // most 2 x 2 tiles (the launcher checks: tile side >= 512 and >= the workgroup's rows): lc = 2 copies x 4 tile slots x 256 bins.
 constexpr int kChSlots = 4, kChCopies = 2;
-template <int GAIN, bool NR, bool GH, bool LUTOK, bool CNR48, bool CH = false>
+#ifndef MUSICA_SD_W
+#define MUSICA_SD_W 3
+#endif
+// SD (levels 0 .. 2 of a context that does not store their sdev images): the launch computes the 5 x 5 RMS of the band image itself, from a
+// window of six band rows it keeps in registers — the bits k_sdev_hist* would have stored (the same sum5 / musica_div25 / musica_sqrt8 on the same
+// squares, sdev_parts.h) — instead of reading them: 4 B per texel less to read here and 4 B less for the sdev launch to write.
+struct BRow {
+    float v[8];     // band columns c .. c+7
+    float e0, e1;   // lane 0: columns c-2, c-1; lane 63: columns c+8, c+9 (0 where the image ends); unused elsewhere
+};
+__device__ __forceinline__ void sdev_from_band(const BRow& r0, const BRow& r1, const BRow& r2, const BRow& r3, const BRow& r4, bool lane0, bool lane63, float (&s)[8]) {
+    float q[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) q[j] = sum5(r0.v[j] * r0.v[j], r1.v[j] * r1.v[j], r2.v[j] * r2.v[j], r3.v[j] * r3.v[j], r4.v[j] * r4.v[j]);
+    const float qe0 = sum5(r0.e0 * r0.e0, r1.e0 * r1.e0, r2.e0 * r2.e0, r3.e0 * r3.e0, r4.e0 * r4.e0);
+    const float qe1 = sum5(r0.e1 * r0.e1, r1.e1 * r1.e1, r2.e1 * r2.e1, r3.e1 * r3.e1, r4.e1 * r4.e1);
+    float a6 = from_left_lane(q[6]), a7 = from_left_lane(q[7]);
+    float b0 = from_right_lane(q[0]), b1 = from_right_lane(q[1]);
+    if (lane0) { a6 = qe0; a7 = qe1; }
+    if (lane63) { b0 = qe0; b1 = qe1; }
+    s[0] = sum5(a6, a7, q[0], q[1], q[2]);
+    s[1] = sum5(a7, q[0], q[1], q[2], q[3]);
+    s[2] = sum5(q[0], q[1], q[2], q[3], q[4]);
+    s[3] = sum5(q[1], q[2], q[3], q[4], q[5]);
+    s[4] = sum5(q[2], q[3], q[4], q[5], q[6]);
+    s[5] = sum5(q[3], q[4], q[5], q[6], q[7]);
+    s[6] = sum5(q[4], q[5], q[6], q[7], b0);
+    s[7] = sum5(q[5], q[6], q[7], b0, b1);
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = musica_div25(s[j]);
+    musica_sqrt8(s);
+}
+template <int GAIN, bool NR, bool GH, bool LUTOK, bool CNR48, bool CH = false, bool SD = false>
 __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds& tab, const LutLds& lut, uint32_t* lh, int img, uint32_t* lc = nullptr,
                                              uint32_t tx0 = 0u, uint32_t ty0 = 0u) {
     constexpr int kGhCopies = 4, kGhStride = MUSICA_GRAD_BINS + 8;
@@ -754,12 +799,14 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
     uint32_t* lcc = CH ? lc + (lane & (kChCopies - 1)) * (kChSlots * MUSICA_CLAHE_BINS) : nullptr;
 
     // One row of a pair once its operands are in registers: contrast gain, noise reduction, addition, store, histograms.
-    auto row_phase = [&](const int ph, float* b, const float* sd, const float* low, const float* f, const uint32_t le_t,
+    // `src` is the band row, `b` the registers the reconstructed row is left in (the same array, or — SD — the lowpass row's: the band row stays
+    // in the window)
+    auto row_phase = [&](const int ph, float* b, const float* src, const float* sd, const float* low, const float* f, const uint32_t le_t,
                          const int kk, const uint32_t w_cnr, const uint32_t w_dark_or_ramp, const bool one_ramp, const bool one_dark) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             // contrast_curve_apply.comp:61
-            float p = b[j] * (GAIN == GAIN_CURVE ? curve_eval_lut<LUTOK>(tab, lut, sd[j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? sd[j] : 0.0f, a.high, tab));
+            float p = src[j] * (GAIN == GAIN_CURVE ? curve_eval_lut<LUTOK>(tab, lut, sd[j]) : gain_of<GAIN>(GAIN != GAIN_CONST ? sd[j] : 0.0f, a.high, tab));
             if (NR) p = p * f[j];   // noise_reduction.comp:57
             b[j] = low[j] + p;      // img_addition.comp:15
         }
@@ -790,6 +837,91 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
             }
         }
     };
+    if constexpr (SD) {
+        // rows 2k - 2 .. 2k + 3 of the band image: six slots that rotate by two rows per trip; three trips are spelled out per loop iteration so
+        // that a slot is a fixed set of registers (no moves). A row outside the image is requested out of range (zeros: Q1).
+        const uint32_t off_e = g.lane0 ? g.off_l : g.off_r;
+        auto load_brow = [&](BRow& r, const int y, const bool wanted) __attribute__((always_inline)) {
+            const uint32_t row_off = (wanted && y >= 0 && y < S) ? (uint32_t)y * rb : kOob;   // wave-uniform
+            load8(r.v, bb, (g.off + row_off) | ((g.off | row_off) & kOob));
+            const float2 e = bload2(bb, (off_e + row_off) | ((off_e | row_off) & kOob));
+            r.e0 = e.x; r.e1 = e.y;
+        };
+        CRow c0, c1, cn;
+        load_crow(c0, pb, (uint32_t)coarse_of_fine(2 * k0 - 2, S) * crb, g);
+        load_crow(c1, pb, (uint32_t)k0 * crb, g);
+        load_crow(cn, pb, (uint32_t)coarse_of_fine(2 * k0 + 2, S) * crb, g);
+        uint32_t le = 0u;
+        float cq[2] = {0.0f, 0.0f};
+        auto load_cnr2 = [&](const int kk) __attribute__((always_inline)) {
+            const size_t re = (size_t)((2 * kk) / cnrScale) * a.cnrPitch;
+            cq[0] = cnr[re + cxs[0]]; cq[1] = cnr[re + cxs[1]];
+        };
+        if (NR && CNR48) load_cnr2(k0);
+        BRow w0, w1, w2, w3, w4, w5;
+        load_brow(w0, 2 * k0 - 2, true); load_brow(w1, 2 * k0 - 1, true); load_brow(w2, 2 * k0, true);
+        load_brow(w3, 2 * k0 + 1, true); load_brow(w4, 2 * k0 + 2, true); load_brow(w5, 2 * k0 + 3, true);
+        if (GH) le = bload_u16(wb, moff + (uint32_t)k0 * mrb);
+        auto trip = [&](const int k, BRow& r0, BRow& r1, BRow& r2, BRow& r3, BRow& r4, BRow& r5) __attribute__((always_inline)) {
+            const bool more = k + 1 < k1;                     // wave-uniform
+            const int kn = k + 1;
+            uint32_t le_n = 0u;
+            if (GH) le_n = bload_u16(wb, (more ? moff : kOob) + (uint32_t)kn * mrb);
+            float lowE[8], lowO[8];
+            lowpass_pair(c0, c1, cn, g, lowE, lowO);
+            c0 = c1; c1 = cn;
+            {
+                const uint32_t row_off = (uint32_t)coarse_of_fine(2 * kn + 2, S) * crb;
+                const float4 q = bload4(pb, (more ? g.coff : kOob) + row_off);
+                cn.v[0] = q.x; cn.v[1] = q.y; cn.v[2] = q.z; cn.v[3] = q.w;
+                cn.hl = cn.hr = bload1(pb, (more ? (g.lane0 ? g.coff_l : g.coff_r) : kOob) + row_off);
+            }
+            float fe[8], fo[8];
+            float cnr_pair = 0.0f;
+            if (NR) {
+                if (CNR48) {
+                    cnr_pair = cq[0] * kMaxCnrValue;
+                    const float e0 = nr_factor_m(cnr_pair, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
+                    const float e1 = nr_factor_m(cq[1] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) { fe[j] = j < 4 ? e0 : e1; fo[j] = fe[j]; }
+                    load_cnr2(more ? kn : k);
+                } else {
+                    const size_t re = (size_t)((2 * k) / cnrScale) * a.cnrPitch, ro = (size_t)((2 * k + 1) / cnrScale) * a.cnrPitch;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int cx = g.active ? (g.c + j) / cnrScale : 0;                 // noise_reduction.comp:39-45
+                        fe[j] = nr_factor_m(cnr[re + cx] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
+                        fo[j] = nr_factor_m(cnr[ro + cx] * kMaxCnrValue, a.lowCnr, a.lowFactor, a.highCnr, a.highFactor, nr_m);
+                    }
+                }
+            }
+            const CnrClass kc = classify_cnr(cnr_pair);
+            const uint32_t w_cnr = kc.ramp ? kc.w_ramp : 0u, w_dark_or_ramp = kc.ramp ? kc.w_ramp : (kc.high ? 100u : 0u);
+            const float r6 = cnr_pair / 6.0f;
+            const bool one_ramp = CH && kc.ramp && (((r6 * r6) * (r6 * r6)) * r6 == 1.0f);
+            const bool one_dark = CH && !kc.ramp && kc.high;
+            {   // even row 2k: window rows 2k - 2 .. 2k + 2, its band values are the centre row's
+                float sd[8];
+                sdev_from_band(r0, r1, r2, r3, r4, g.lane0, g.lane63, sd);
+                row_phase(0, lowE, r2.v, sd, lowE, fe, le, k, w_cnr, w_dark_or_ramp, one_ramp, one_dark);
+            }
+            load_brow(r0, 2 * k + 4, more);   // the slot of row 2k - 2 takes row 2k + 4 (the next trip's; nothing if there is none)
+            {   // odd row 2k + 1: rows 2k - 1 .. 2k + 3
+                float sd[8];
+                sdev_from_band(r1, r2, r3, r4, r5, g.lane0, g.lane63, sd);
+                row_phase(1, lowO, r3.v, sd, lowO, fo, le, k, w_cnr, w_dark_or_ramp, one_ramp, one_dark);
+            }
+            load_brow(r1, 2 * k + 5, more);
+            le = le_n;
+        };
+        for (int k = k0; k < k1; k += 3) {
+            trip(k, w0, w1, w2, w3, w4, w5);
+            if (k + 1 < k1) trip(k + 1, w2, w3, w4, w5, w0, w1);
+            if (k + 2 < k1) trip(k + 2, w4, w5, w0, w1, w2, w3);
+        }
+        return saw_zero;
+    }
     // The march is a software pipeline (round 4): while a wavefront computes one row of a pair, the operands of its NEXT row are in
     // flight — the odd row's band / sdev registers are requested before the even row is computed, the next trip's even row into the even
     // row's registers as soon as that row is stored, the next trip's coarse row into the registers of the coarse row that has just left
@@ -865,18 +997,18 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
         // lookup — up into the even row's phase, and the wait for the odd row with them. __builtin_amdgcn_sched_barrier(0) in front of
         // either phase keeps them apart, and costs more than it saves: 153 registers, i.e. 84 bytes of scratch at 4 wavefronts per SIMD
         // (116 us) or 3 wavefronts per SIMD (85.9 us, the same as this form: 85.2 - 87.2 against 89.4 - 89.7 us before the pipeline).)
-        row_phase(0, be, se, lowE, fe, le, k, w_cnr, w_dark_or_ramp, one_ramp, one_dark);
+        row_phase(0, be, be, se, lowE, fe, le, k, w_cnr, w_dark_or_ramp, one_ramp, one_dark);
         // the even row of the next trip into the registers the even row has just left
         load8(be, bb, goff_n + (uint32_t)(2 * kn) * rb);
         if (GAIN != GAIN_CONST) load8(se, sb, goff_n + (uint32_t)(2 * kn) * rb);
-        row_phase(1, bo, so, lowO, fo, le, k, w_cnr, w_dark_or_ramp, one_ramp, one_dark);
+        row_phase(1, bo, bo, so, lowO, fo, le, k, w_cnr, w_dark_or_ramp, one_ramp, one_dark);
         le = le_n;
     }
     }
     return saw_zero;
 }
 
-template <int GAIN, bool NR, bool GH, int W = 1, bool CH = false>
+template <int GAIN, bool NR, bool GH, int W = 1, bool CH = false, bool SD = false>
 __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) {
     __shared__ CurveLds tab;
     __shared__ __attribute__((aligned(16))) LutLds lut;
@@ -908,10 +1040,10 @@ __global__ __launch_bounds__(kBlockThreads, W) void k_expand_fast(ExpandArgs a) 
     const bool lut_ok = GAIN != GAIN_CURVE || __builtin_amdgcn_readfirstlane((int)lut.ok) != 0;
     const bool cnr48 = !NR || GH || a.cnrScale == 4 || a.cnrScale == 8;   // kernel argument: uniform
     bool saw_zero;
-    if (lut_ok && cnr48) saw_zero = expand_march<GAIN, NR, GH, true, true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
-    else if (lut_ok) saw_zero = expand_march<GAIN, NR, GH, true, NR && !GH ? false : true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
-    else if (cnr48) saw_zero = expand_march<GAIN, NR, GH, GAIN != GAIN_CURVE, true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
-    else saw_zero = expand_march<GAIN, NR, GH, GAIN != GAIN_CURVE, NR && !GH ? false : true, CH>(a, tab, lut, lh, img, lc, tx0, ty0);
+    if (lut_ok && cnr48) saw_zero = expand_march<GAIN, NR, GH, true, true, CH, SD>(a, tab, lut, lh, img, lc, tx0, ty0);
+    else if (lut_ok) saw_zero = expand_march<GAIN, NR, GH, true, NR && !GH ? false : true, CH, SD>(a, tab, lut, lh, img, lc, tx0, ty0);
+    else if (cnr48) saw_zero = expand_march<GAIN, NR, GH, GAIN != GAIN_CURVE, true, CH, SD>(a, tab, lut, lh, img, lc, tx0, ty0);
+    else saw_zero = expand_march<GAIN, NR, GH, GAIN != GAIN_CURVE, NR && !GH ? false : true, CH, SD>(a, tab, lut, lh, img, lc, tx0, ty0);
     if (GH) {
         if (saw_zero) atomicOr(&a.gzero[img], 1u);
         __syncthreads();
@@ -1000,6 +1132,7 @@ __global__ void k_exp_band_generic(ExpandArgs a) {
 // taps per texel — from the XCD's L2, where the workgroup's own stores land, that is 25 round trips of ~1 us) and every result is
 // also stored to its global image (the getters, and the expand slot of level T - 1, read those).
 constexpr int kTailPool = 3 * (kTailSide * kTailSide + (kTailSide / 2) * (kTailSide / 2) * 2) + 64;   // fine + band + recon of every level (sum of squares < 1.5 x the first)
+#ifdef MUSICA_PYRAMID_FULL
 __global__ __launch_bounds__(1024) void k_tiny_tail(const TailArgs a) {
     __shared__ float pool[kTailPool];
     // side of level k (k = n: the coarsest image) and where its fine, band and reconstruction images sit in the pool. Rolled
@@ -1079,6 +1212,26 @@ __global__ __launch_bounds__(1024) void k_tiny_tail(const TailArgs a) {
 // host-side launchers
 // ======================================================================================
 
+#endif   // MUSICA_PYRAMID_FULL (k_tiny_tail)
+static inline dim3 stream_grid(int S, int rows, int rows_per_wave, int batch) {
+    const int strips = (S + kStripCols - 1) / kStripCols;
+    const int segs = (rows + rows_per_wave - 1) / rows_per_wave;
+    return dim3(strips, (segs + kWavesPerBlock - 1) / kWavesPerBlock, batch);
+}
+
+#ifndef MUSICA_PYRAMID_FULL
+// The expand launch of a level whose sdev image is not stored (a.sdev == nullptr; GAIN_CURVE levels 0 .. 2): kernels_pyramid.hip's
+// launch_expand hands those over to this translation unit.
+void launch_expand_sd(hipStream_t st, const ExpandArgs& a, bool nr, int batch) {
+    const dim3 grid = stream_grid(a.S, a.Sc, a.rows_per_wave, batch);
+    if (nr && a.ghist) {
+        if (a.chist) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, true, MUSICA_SD_W, true, true>), grid, dim3(kBlockThreads), 0, st, a);
+        else hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, true, MUSICA_SD_W, false, true>), grid, dim3(kBlockThreads), 0, st, a);
+    }
+    else if (nr) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, false, MUSICA_SD_W, false, true>), grid, dim3(kBlockThreads), 0, st, a);
+    else hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, false, false, MUSICA_SD_W, false, true>), grid, dim3(kBlockThreads), 0, st, a);
+}
+#else
 void launch_tiny_tail(hipStream_t st, const TailArgs& a, int batch) {
     hipLaunchKernelGGL(k_tiny_tail, dim3(batch), dim3(1024), 0, st, a);
 }
@@ -1091,11 +1244,6 @@ int xcd_swizzle_on() {
 static int region_map_on() {   // MUSICA_XCD_REGIONS=0: the round-3 tile mapping of the metric kernel
     static const int on = getenv("MUSICA_XCD_REGIONS") ? atoi(getenv("MUSICA_XCD_REGIONS")) : 1;
     return on;
-}
-static inline dim3 stream_grid(int S, int rows, int rows_per_wave, int batch) {
-    const int strips = (S + kStripCols - 1) / kStripCols;
-    const int segs = (rows + rows_per_wave - 1) / rows_per_wave;
-    return dim3(strips, (segs + kWavesPerBlock - 1) / kWavesPerBlock, batch);
 }
 static inline dim3 generic_grid(int S, int batch) { return dim3((S + 31) / 32, (S + 7) / 8, batch); }
 static const dim3 kGenericBlock(32, 8, 1);
@@ -1148,6 +1296,10 @@ void launch_lowpass(hipStream_t st, const float* coarse, float* low, const Level
 
 template <int GAIN, bool NR>
 static void launch_expand_t(hipStream_t st, const ExpandArgs& a, int batch, bool force_generic) {
+    if (GAIN == GAIN_CURVE && !a.sdev) {   // the level's sdev image is not stored: the launch computes sdev itself (k_expand_fast<.., SD>, kernels_expand_sd.hip)
+        launch_expand_sd(st, a, NR, batch);
+        return;
+    }
     if (fast_ok(a.S) && !force_generic) {
         const dim3 grid = stream_grid(a.S, a.Sc, a.rows_per_wave, batch);
         if (GAIN == GAIN_CURVE && NR && a.ghist) {   // level 0 with the gradation histogram on board (the caller checked cnrScale == 8 and passes le090)
@@ -1176,5 +1328,6 @@ void launch_exp_band(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr
     else if (nr) hipLaunchKernelGGL((k_exp_band_generic<GAIN_CURVE, true>), g, kGenericBlock, 0, st, a);
     else hipLaunchKernelGGL((k_exp_band_generic<GAIN_CURVE, false>), g, kGenericBlock, 0, st, a);
 }
+#endif   // MUSICA_PYRAMID_FULL (launchers)
 
 }  // namespace musica

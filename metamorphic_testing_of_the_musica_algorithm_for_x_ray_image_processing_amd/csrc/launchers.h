@@ -69,6 +69,7 @@ void launch_reduce_band_u16(hipStream_t st, const uint16_t* px, float* down, flo
 void launch_reduce_band(hipStream_t st, const float* fine, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave);
 void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch, int ref = 0);
 void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic);
+void launch_expand_sd(hipStream_t st, const ExpandArgs& a, bool nr, int batch);   // a.sdev == nullptr: sdev computed by the launch (kernels_expand_sd.hip)
 // reduce + band of the levels in `a`, then their expand slots, one workgroup per image (levels of side <= kTailSide)
 void launch_tiny_tail(hipStream_t st, const TailArgs& a, int batch);
 void launch_exp_band(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch);
@@ -89,6 +90,7 @@ void launch_sdev_hist_runs(hipStream_t st, int n, const float* const* band, floa
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch);
 // img_sdev.comp:10-35 with the 25 squares accumulated in the shader's order (one thread per texel; MUSICA_FLAG_REFERENCE_ORDER)
 void launch_sdev_literal(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, int batch);
+void launch_sdev_only(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, int batch);   // the fast order's sdev image alone (no histogram)
 void launch_noise_curves(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves, const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const uint32_t* minmax, int min_chain_exact, int* thr090, int lev0 = 0, int nlev = 0);
 void launch_curves_cnr(hipStream_t st, const uint32_t* hist, size_t hist_stride, musica_hist_max_point* maxpts, DevCurve* curves,
                        const musica_contrast_params* cparams, int levels, int batch, DevCurveLut* luts, const float* sdev, float* cnr,

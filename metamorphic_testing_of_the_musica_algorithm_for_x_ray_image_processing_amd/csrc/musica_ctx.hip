@@ -117,6 +117,10 @@ struct musica_ctx {
     double* d_stats_partial;   // [B][kStatsMaxBlocks]: partial sums of the cnr image (k_stats_partial -> k_stats)
     uint16_t* d_le090;         // [B][S1][S0 / 8] or null: its bit image, written by the level-0 reduce + band launch for the level-0 expand launch
     bool fuse_gh;              // the level-0 expand launch accumulates the gradation histogram
+    // The expand launches of levels 0 .. 2 compute the 5 x 5 RMS of their band image themselves (k_expand_fast<.., SD>) and the sdev +
+    // noise-histogram launches of those levels store nothing: 8 of a step's 48 bytes per input pixel. The whole-step scripts run that way
+    // (sd_active); the stage entry points, getters and dumps want the stored images: ensure_sdev() writes them on demand.
+    bool sd_fused, sd_active, sdev_stored;
     int rows_rb[MUSICA_MAX_LEVELS];   // its coarse rows per wavefront
     musica_hist_max_point* d_grad_max;
     DevCurve* d_gcurve;
@@ -435,6 +439,18 @@ static musica_ctx* create_impl(const musica_params* params, const musica_tunable
     c->clahe_one_apply = env_int("MUSICA_CLAHE_ONE_APPLY", 1) != 0;
     c->tiny_tail = env_int("MUSICA_TINY_TAIL", 1) != 0;
     c->grad_one_launch = env_int("MUSICA_GRAD_ONE_LAUNCH", 1) != 0;
+    {
+        // sdev computed inside the expand launches of levels 0 .. 2 (k_expand_fast<.., SD>) instead of stored by the sdev launch and read back:
+        // 8 of a step's 48 bytes per input pixel against ~35 % more vector work in those expand launches. It pays where a step is bound by its
+        // bytes — steps in flight (the contexts of a pipeline: MUSICA_FLAG_LINEAR) from 2 x 2048^2 texels per step, a lone context from
+        // 8 x 2048^2 (same-box A/B, three steps in flight / one context: 8 x 2048^2 -7.8 % / -0.8 %, 8192^2 -12.4 % / -5.7 %, 4 x 2048^2
+        // -2.6 %, 3072^2 L12 -2.0 % / +4.1 %, one 2048^2 image +2.5 % / +6.6 %) — and not in CLAHE contexts (that instantiation does not fit
+        // 168 registers: 4096^2 + CLAHE +4.7 % / +11.6 %). MUSICA_SDEV_IN_EXPAND=0 | 1 overrides.
+        const size_t texels = (size_t)c->B * N * N;
+        const bool pays = !(params->flags & MUSICA_FLAG_CLAHE) && texels >= ((params->flags & MUSICA_FLAG_LINEAR) ? (size_t)2 : (size_t)8) * 2048 * 2048;
+        c->sd_fused = env_int("MUSICA_SDEV_IN_EXPAND", pays ? 1 : 0) != 0 && !c->generic;
+    }
+    c->sd_active = false; c->sdev_stored = true;
     c->fuse_gh = env_int("MUSICA_FUSE_GH", 1) != 0 && c->fuse_u16 && (!(params->flags & MUSICA_FLAG_CLAHE) || c->clahe_raw) &&
                  cnr_scale(c->lv[0].S, c->lv[MUSICA_CNR_LEVEL].S) == 8;
     tick.lap("streams + events");
@@ -507,6 +523,7 @@ int musica_get_dispatch(const musica_ctx* c, int* streams, int* graph) {
 }
 int musica_fuses_gradation_histogram(const musica_ctx* c) { return (c && c->fuse_gh && !c->generic) ? 1 : 0; }
 int musica_fuses_reduce_band(const musica_ctx* c) { return (c && rb_level(c, 0)) ? 1 : 0; }
+int musica_fuses_sdev(const musica_ctx* c) { return (c && c->sd_fused && rb_level(c, 0)) ? 1 : 0; }
 uint32_t musica_get_level_size(const musica_ctx* c, uint32_t level) { return (c && (int)level <= c->L) ? (uint32_t)c->lv[level].S : 0; }
 
 }  // extern "C"
@@ -584,14 +601,24 @@ static void run_reduce_and_band(musica_ctx* c, int i) {
     { Span sp(c, i == 0 ? MUSICA_KERNEL_REDUCE_L0 : MUSICA_KERNEL_REDUCE_REST); launch_reduce(c->cur, level_input(c, i), c->lv[i], c->d_down[i], c->lv[i + 1], c->B, true, i == 0 ? 0 : 1, c->ref_order); }
     { Span sp(c, i == 0 ? MUSICA_KERNEL_BAND_L0 : MUSICA_KERNEL_BAND_REST); launch_band(c->cur, level_input(c, i), c->d_down[i], c->d_band[i], c->lv[i], c->lv[i + 1], c->B, c->ref_order); }
 }
+// level i's sdev image is neither stored nor read by this step: its expand launch computes it (levels below the cnr level whose side
+// takes the streaming kernels)
+static bool sd_level(const musica_ctx* c, int i) { return c->sd_active && i < MUSICA_CNR_LEVEL && rb_level(c, i); }
 static void run_sdev_level(musica_ctx* c, int i, int rows) {
     if (c->ref_order) {   // img_sdev.comp literally, then noise_hist.comp on the stored image
         launch_sdev_literal(c->cur, c->d_band[i], c->d_sdev[i], c->lv[i], c->B);
         launch_noise_hist_only(c->cur, c->d_sdev[i], c->lv[i], c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS, (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov, c->B);
         return;
     }
-    launch_sdev_hist(c->cur, c->d_band[i], c->d_sdev[i], c->lv[i], c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS,
+    launch_sdev_hist(c->cur, c->d_band[i], sd_level(c, i) ? nullptr : c->d_sdev[i], c->lv[i], c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS,
                      (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov, c->B, rows);
+}
+// The stored sdev images of levels whose hot path does not store them (getters, dumps, stage entry points, the generic kernels).
+static void ensure_sdev(musica_ctx* c) {
+    if (c->sdev_stored) return;
+    for (int i = 0; i < MUSICA_CNR_LEVEL && i < c->L; i++)
+        if (rb_level(c, i)) launch_sdev_only(c->stream, c->d_band[i], c->d_sdev[i], c->lv[i], c->B);
+    c->sdev_stored = true;
 }
 
 // The first level of the tiny tail (k_tiny_tail: reduce + band of levels T .. L-1 and their expand slots in one launch), L if none:
@@ -642,7 +669,7 @@ static void run_sdev_levels(musica_ctx* c, int first) {
     LevelDesc lv[kSdevRunLevelsMax];
     int n = 0;
     for (int i = first; i <= MUSICA_CNR_LEVEL; i++, n++) {
-        band[n] = c->d_band[i]; sdev[n] = c->d_sdev[i]; lv[n] = c->lv[i];
+        band[n] = c->d_band[i]; sdev[n] = sd_level(c, i) ? nullptr : c->d_sdev[i]; lv[n] = c->lv[i];
         hist[n] = c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS;
     }
     launch_sdev_hist_runs(c->cur, n, band, sdev, lv, hist, (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov, c->B);
@@ -680,7 +707,7 @@ static ExpandArgs expand_args(musica_ctx* c, int lvl, float* dst) {
     ExpandArgs a;
     a.prev = lvl == c->L - 1 ? c->d_down[c->L - 1] : c->d_recon[lvl + 1];  // src/vk_processing.cpp:930-934
     a.band = c->d_band[lvl];
-    a.sdev = lvl <= MUSICA_CNR_LEVEL ? c->d_sdev[lvl] : nullptr;
+    a.sdev = lvl <= MUSICA_CNR_LEVEL && !sd_level(c, lvl) ? c->d_sdev[lvl] : nullptr;
     a.cnr = c->d_cnr;
     a.recon = dst;
     a.curves = c->d_curves + lvl;
@@ -812,8 +839,11 @@ static void enqueue_fork(musica_ctx* c) {
     enqueue_gradation(c, true);
 }
 static void enqueue_script(musica_ctx* c) {
+    c->sd_active = c->sd_fused;
     if (c->dag) enqueue_fork(c);
     else enqueue_linear(c);
+    if (c->sd_active) c->sdev_stored = false;
+    c->sd_active = false;
 }
 
 // Captures the dispatch script (with two streams the side stream joins the capture through ev_fork and rejoins
@@ -869,6 +899,7 @@ static int enqueue_all_impl(musica_ctx* c) {
         if (k >= 0) {
             c->graph_used[k] = ++c->graph_clock;
             c->norm_valid = (c->d_clahe_hist != nullptr && !c->clahe_raw) || !c->fuse_u16;
+            if (c->sd_fused) c->sdev_stored = false;
             if (hipGraphLaunch(c->graph_exec[k], c->stream) != hipSuccess) return fail("hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError()));
             return 1;
         }
@@ -921,6 +952,7 @@ static void autotune(musica_ctx* c) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
     c->tuning = true;
+    c->sd_active = c->sd_fused;   // the forms the whole-step scripts run
     const int reps = 3;
     static const int cand_pair[] = {2, 4, 8, 16};   // band / expand count coarse rows (two fine rows each)
     static const int cand_sdev[] = {0, 16, 32, 64};   // 0: one run per workgroup
@@ -943,6 +975,8 @@ static void autotune(musica_ctx* c) {
         }
     }
     c->tuning = false;
+    if (c->sd_active) c->sdev_stored = false;
+    c->sd_active = false;
     hipEventDestroy(a);
     hipEventDestroy(b);
     hipStreamSynchronize(c->stream);
@@ -1111,6 +1145,7 @@ static int enqueue_images_from_host(musica_ctx* c, uint16_t* d_dst, const uint16
     }
     c->cur_input = d_dst;
     c->norm_valid = c->lanes[0]->norm_valid;
+    if (c->sd_fused) c->sdev_stored = false;
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { c->needs_reset = true; return fail("per-image dispatch failed: %s", hipGetErrorString(e)); }
     return 1;
@@ -1249,7 +1284,7 @@ int musica_debug_run_stage(musica_ctx* c, musica_stage stage) {
             launch_clear(c->stream, nullptr, c->d_noise_hist, nullptr, nullptr, c->B);
             enqueue_analysis(c);
             break;
-        case MUSICA_STAGE_EXPAND: enqueue_expand(c, false); break;
+        case MUSICA_STAGE_EXPAND: ensure_sdev(c); enqueue_expand(c, false); break;
         case MUSICA_STAGE_GRADATION:
             launch_clear(c->stream, nullptr, nullptr, c->d_grad_hist, c->d_clahe_hist, c->B, c->d_grad_hist_b, c->d_gzero);
             enqueue_gradation(c, false);
@@ -1291,6 +1326,7 @@ static int resolve_image(musica_ctx* c, uint32_t idx, musica_image_kind kind, ui
         case MUSICA_IMG_EXPAND: *plane = c->d_recon[level] + idx * c->lv[level].plane; *desc = &c->lv[level]; return 1;
         case MUSICA_IMG_SDEV:
             *desc = &c->lv[level];
+            ensure_sdev(c);
             if (level <= MUSICA_CNR_LEVEL) { *plane = c->d_sdev[level] + idx * c->lv[level].plane; return 1; }
             // levels >= 4: the reference never writes these images (src/vk_processing.cpp:2285) -> zeros (Q2)
             HIP_OK(hipMemsetAsync(c->d_scratch, 0, c->lv[level].plane * sizeof(float), c->stream));
@@ -1306,6 +1342,7 @@ static int resolve_image(musica_ctx* c, uint32_t idx, musica_image_kind kind, ui
             launch_lowpass(c->stream, c->d_down[level], c->d_scratch, c->lv[level], c->lv[level + 1], c->B, c->ref_order);
             *plane = c->d_scratch + idx * c->lv[level].plane; *desc = &c->lv[level]; return 1;
         case MUSICA_IMG_EXP_BANDPASS: case MUSICA_IMG_CONTRAST_BAND: {
+            ensure_sdev(c);
             const ExpandArgs a = expand_args(c, (int)level, c->d_scratch);
             launch_exp_band(c->stream, a, gain_mode((int)level), kind == MUSICA_IMG_EXP_BANDPASS && uses_nr((int)level), c->B);
             *plane = c->d_scratch + idx * c->lv[level].plane; *desc = &c->lv[level]; return 1;
@@ -1338,6 +1375,7 @@ int musica_debug_set_image(musica_ctx* c, uint32_t idx, musica_image_kind kind, 
         case MUSICA_IMG_EXPAND: return upload_plane(c, c->d_recon[level] + idx * c->lv[level].plane, c->lv[level], src);
         case MUSICA_IMG_SDEV:
             if (level > MUSICA_CNR_LEVEL) return fail("musica_debug_set_image: sdev exists only for levels 0..3");
+            ensure_sdev(c);   // the other levels' stored images first: a later getter must not overwrite what the caller sets here
             return upload_plane(c, c->d_sdev[level] + idx * c->lv[level].plane, c->lv[level], src);
         default: return fail("musica_debug_set_image: kind %d is not stored on the hot path", (int)kind);
     }

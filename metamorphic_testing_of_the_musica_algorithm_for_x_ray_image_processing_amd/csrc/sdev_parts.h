@@ -163,10 +163,10 @@ __device__ __forceinline__ void sdev_store(const float (&s)[8], const SCfg& g, f
 template <bool HIST, bool A8>
 __device__ __forceinline__ void sdev_row(const SRow& r0, const SRow& r1, const SRow& r2, const SRow& r3, const SRow& r4, const SCfg& g, int S,
                                          int y, int cov, float* __restrict__ drow, const Buf& db, uint32_t row_off, uint32_t* lh,
-                                         unsigned long long (&alive)[8], const unsigned long long (&start)[8]) {
+                                         unsigned long long (&alive)[8], const unsigned long long (&start)[8], bool store = true) {
     float s[8];
     sdev_values(r0, r1, r2, r3, r4, g, s);
-    sdev_store<A8>(s, g, drow, db, row_off);
+    if (store) sdev_store<A8>(s, g, drow, db, row_off);   // wave-uniform: a level whose expand launch computes sdev itself only needs the histogram
     // noise_hist.comp:20-47, branch-free. A run adds until its first `break` (bin 0): alive[j] afterwards is exactly
     // "this texel is counted". A dead column adds into the lane's scratch word; bin 2048 (out of the histogram
     // image, dropped by Q1 without breaking) is a pad word behind the copy (never flushed), so it needs no test of its own. Columns

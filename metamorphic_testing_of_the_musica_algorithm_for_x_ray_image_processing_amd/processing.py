@@ -124,6 +124,7 @@ ABI = {
     "musica_get_level_size": (C.c_uint32, [_VP, C.c_uint32]),
     "musica_fuses_gradation_histogram": (C.c_int, [_VP]),
     "musica_fuses_reduce_band": (C.c_int, [_VP]),
+    "musica_fuses_sdev": (C.c_int, [_VP]),
     "musica_get_dispatch": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "musica_execute": (C.c_int, [_VP, _U16P]),
     "musica_execute_device": (C.c_int, [_VP, _VP]),
@@ -470,6 +471,10 @@ class MusicaProcessing:
     def fuses_gradhist(self):
         """True when the level-0 expand kernel also accumulates the gradation histogram (no separate k_grad_hist launch)."""
         return self._lib.musica_fuses_gradation_histogram(self._h) == 1
+
+    def fuses_sdev(self):
+        """True when the expand launches of levels 0 .. 2 compute sdev themselves and the sdev launches of those levels store nothing."""
+        return self._lib.musica_fuses_sdev(self._h) == 1
 
     def fuses_reduce_band(self):
         """True when level 0's reduce and band kernels are one launch (profile family `reduce_l0` covers both)."""

@@ -591,6 +591,51 @@ def test_save_out_image_and_debug_process(ob, tmp_path):
     p.cleanup()
 
 
+@pytest.mark.parametrize("n,levels,batch,flags", [(1032, 6, 1, 0), (1032, 6, 3, 0), (520, 4, 2, 0), (2048, 6, 1, 0), (1024, 5, 1, "clahe"), (2056, 7, 1, "linear"), (264, 4, 1, 0)])
+def test_sdev_inside_the_expand_launches(ob, n, levels, batch, flags, monkeypatch):
+    """MUSICA_SDEV_IN_EXPAND=1 (the default of byte-bound workloads: steps in flight from 2 x 2048^2 texels, a lone context from 8 x 2048^2):
+    the expand launches of levels 0 .. 2 compute the 5 x 5 RMS of their band image in registers (k_expand_fast<.., SD>, a window of six band
+    rows) and the sdev launches of those levels store nothing. Everything against the oracle, twice in a row, in both launch modes; the sdev
+    images themselves come from the getters' on-demand launch. Sides with 1, 2 and 3 strips, segments that end inside the image, a level
+    of 33 rows (264 / 8), batches, CLAHE (the instantiation that also counts the CLAHE histogram) and a one-stream context.
+    Then the stage entry points on the same context: they use the stored images (an injected sdev image must reach the expand stage)."""
+    f = {0: 0, "clahe": mp.FLAG_CLAHE, "linear": mp.FLAG_LINEAR}[flags]
+    px = np.stack([phantom(n, 300 + k) for k in range(batch)])
+    of = ob.FLAG_CLAHE if flags == "clahe" else 0
+    want = [ob.Oracle(n, levels, ob.ORDER_FAST, of).execute(px[k]) for k in range(batch)]
+    monkeypatch.setenv("MUSICA_SDEV_IN_EXPAND", "1")
+    for graph in ("1", "0"):
+        monkeypatch.setenv("MUSICA_GRAPH", graph)
+        p = _proc(n, levels, batch=batch, flags=f)
+        assert p.fuses_sdev()
+        for rep in range(2):
+            assert p.execute(px)
+        for k in range(batch):
+            _compare_all(p, want[k], ob, idx=k, tag="sdev in expand, graph %s, image %d: " % (graph, k))
+        p.cleanup()
+    monkeypatch.setenv("MUSICA_SDEV_IN_EXPAND", "0")
+    p = _proc(n, levels, batch=batch, flags=f)
+    assert not p.fuses_sdev()
+    p.cleanup()
+    # stage entry points after a whole-step execute: sdev level 1 replaced by a constant image -> the expand stage must see it
+    monkeypatch.setenv("MUSICA_SDEV_IN_EXPAND", "1")
+    p = _proc(n, levels, batch=batch, flags=f)
+    assert p.execute(px)
+    s1 = p.image(mp.IMG_SDEV, 1, 0)
+    _same(s1, want[0].image(ob.IMG_SDEV, 1), "sdev[1] on demand")
+    fake = np.full_like(s1, 0.004)
+    p.set_image(mp.IMG_SDEV, 1, fake, 0)
+    _same(p.image(mp.IMG_SDEV, 0, 0), want[0].image(ob.IMG_SDEV, 0), "sdev[0] kept")
+    p.run_stage(mp.STAGE_EXPAND)
+    o2 = ob.Oracle(n, levels, ob.ORDER_FAST, of).execute(px[0])
+    o2.set_image(ob.IMG_SDEV, 1, fake)
+    o2.run_stage(ob.STAGE_EXPAND)
+    _same(p.image(mp.IMG_EXPAND, 0, 0), o2.image(ob.IMG_EXPAND, 0), "expand[0] from the injected sdev[1]")
+    assert p.execute(px)   # and the next whole step computes its own again
+    _same(p.image(mp.IMG_EXPAND, 0, 0), want[0].image(ob.IMG_EXPAND, 0), "expand[0] after the next step")
+    p.cleanup()
+
+
 @pytest.mark.parametrize("n", [64, 533, 534, 535])
 def test_save_out_image_rows_built_on_the_device(ob, n, tmp_path, monkeypatch):
     """saveOutImage's file image — header by the host, 24-bpp bottom-up padded rows by k_out_bmp24 straight into page-locked memory, one
