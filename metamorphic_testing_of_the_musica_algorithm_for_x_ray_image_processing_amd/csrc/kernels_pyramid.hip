@@ -725,6 +725,9 @@ constexpr int kChSlots = 4, kChCopies = 2;
 #ifndef MUSICA_SD_W
 #define MUSICA_SD_W 3
 #endif
+#ifndef MUSICA_SD_CH_W
+#define MUSICA_SD_CH_W 2   // with the CLAHE histogram on board the launch wants 189 registers: 64 bytes of scratch at 3 wavefronts per SIMD
+#endif
 // SD (levels 0 .. 2 of a context that does not store their sdev images): the launch computes the 5 x 5 RMS of the band image itself, from a
 // window of six band rows it keeps in registers — the bits k_sdev_hist* would have stored (the same sum5 / musica_div25 / musica_sqrt8 on the same
 // squares, sdev_parts.h) — instead of reading them: 4 B per texel less to read here and 4 B less for the sdev launch to write.
@@ -1225,7 +1228,7 @@ static inline dim3 stream_grid(int S, int rows, int rows_per_wave, int batch) {
 void launch_expand_sd(hipStream_t st, const ExpandArgs& a, bool nr, int batch) {
     const dim3 grid = stream_grid(a.S, a.Sc, a.rows_per_wave, batch);
     if (nr && a.ghist) {
-        if (a.chist) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, true, MUSICA_SD_W, true, true>), grid, dim3(kBlockThreads), 0, st, a);
+        if (a.chist) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, true, MUSICA_SD_CH_W, true, true>), grid, dim3(kBlockThreads), 0, st, a);
         else hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, true, MUSICA_SD_W, false, true>), grid, dim3(kBlockThreads), 0, st, a);
     }
     else if (nr) hipLaunchKernelGGL((k_expand_fast<GAIN_CURVE, true, false, MUSICA_SD_W, false, true>), grid, dim3(kBlockThreads), 0, st, a);

@@ -444,10 +444,9 @@ static musica_ctx* create_impl(const musica_params* params, const musica_tunable
         // 8 of a step's 48 bytes per input pixel against ~35 % more vector work in those expand launches. It pays where a step is bound by its
         // bytes — steps in flight (the contexts of a pipeline: MUSICA_FLAG_LINEAR) from 2 x 2048^2 texels per step, a lone context from
         // 8 x 2048^2 (same-box A/B, three steps in flight / one context: 8 x 2048^2 -7.8 % / -0.8 %, 8192^2 -12.4 % / -5.7 %, 4 x 2048^2
-        // -2.6 %, 3072^2 L12 -2.0 % / +4.1 %, one 2048^2 image +2.5 % / +6.6 %) — and not in CLAHE contexts (that instantiation does not fit
-        // 168 registers: 4096^2 + CLAHE +4.7 % / +11.6 %). MUSICA_SDEV_IN_EXPAND=0 | 1 overrides.
+        // -2.6 %, 3072^2 L12 -5.0 % / +4.1 %, 4096^2 + CLAHE -1.5 % / +2.5 %, one 2048^2 image +2.5 % / +6.6 %). MUSICA_SDEV_IN_EXPAND=0 | 1 overrides.
         const size_t texels = (size_t)c->B * N * N;
-        const bool pays = !(params->flags & MUSICA_FLAG_CLAHE) && texels >= ((params->flags & MUSICA_FLAG_LINEAR) ? (size_t)2 : (size_t)8) * 2048 * 2048;
+        const bool pays = texels >= ((params->flags & MUSICA_FLAG_LINEAR) ? (size_t)2 : (size_t)8) * 2048 * 2048;
         c->sd_fused = env_int("MUSICA_SDEV_IN_EXPAND", pays ? 1 : 0) != 0 && !c->generic;
     }
     c->sd_active = false; c->sdev_stored = true;
