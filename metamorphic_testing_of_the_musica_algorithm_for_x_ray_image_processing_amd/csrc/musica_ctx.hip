@@ -1282,6 +1282,7 @@ int musica_debug_run_stage(musica_ctx* c, musica_stage stage) {
         case MUSICA_STAGE_ANALYSIS:
             launch_clear(c->stream, nullptr, c->d_noise_hist, nullptr, nullptr, c->B);
             enqueue_analysis(c);
+            c->sdev_stored = true;   // the stage stores every level's sdev image (sd_active is a property of the whole-step scripts)
             break;
         case MUSICA_STAGE_EXPAND: ensure_sdev(c); enqueue_expand(c, false); break;
         case MUSICA_STAGE_GRADATION:
