@@ -75,8 +75,9 @@ __device__ __forceinline__ void bstore4(const Buf& b, uint32_t off, float4 v) {
     llvm_buffer_store_v4f32(u, b.r, (int)off, 0, 0);
 }
 // Non-temporal form (aux bit 1 = nt): for kernels that read several bytes per byte they write and do not read their output
-// again (the metric kernel, reduce + band). Measured per kernel, not a blanket rule: the 1:1 streams (sdev, gradation apply)
-// and the expand launches are 5 - 20 % slower with it (round 3).
+// again (the metric kernel, reduce + band). Measured per kernel, not a blanket rule: alone on the chip the sdev launch is 5 - 20 %
+// slower with it (round 3), and so were the expand launches and the gradation apply then; with steps in flight
+// (round 4, same-box A/B of whole steps) the reconstruction and graded stores are 4 % of a step faster non-temporal and a lone context is no slower.
 __device__ __forceinline__ void bstore4_nt(const Buf& b, uint32_t off, float4 v) {
     v4f u;
     u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;

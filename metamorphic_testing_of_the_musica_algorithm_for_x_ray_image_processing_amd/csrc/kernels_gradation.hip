@@ -407,7 +407,14 @@ __device__ __forceinline__ void grad_apply_loop(const CurveLds& tab, const GradL
             if (nxt + u * stride < total) w[u] = src[nxt + u * stride];   // the next trip's groups, in flight during the lookups
 #pragma unroll
         for (int u = 0; u < U; u++)
-            if (i + u * stride < total) dst[i + u * stride] = grad_eval4<MONO>(tab, gl, last_b, x0, y0, v[u]);
+            // non-temporal (round 4): nothing of the step reads the graded image again; with three steps in flight 8 x 2048^2 -2.1 % per step, and
+            // -4.2 % together with the reconstruction stores of the expand launches (same-box A/B, profiles/r04_expand_pipeline.txt); a lone context:
+            // equal or 1 % better (round 3 had measured this launch 5 - 10 % slower alone with non-temporal stores: before its loads were prefetched)
+            if (i + u * stride < total) {
+                const float4 r_ = grad_eval4<MONO>(tab, gl, last_b, x0, y0, v[u]);
+                v4f q_; q_.x = r_.x; q_.y = r_.y; q_.z = r_.z; q_.w = r_.w;
+                __builtin_nontemporal_store(q_, reinterpret_cast<v4f*>(&dst[i + u * stride]));
+            }
 #pragma unroll
         for (int u = 0; u < U; u++) v[u] = w[u];
         i = nxt;

@@ -813,7 +813,7 @@ __device__ __forceinline__ bool expand_march(const ExpandArgs& a, const CurveLds
             if (NR) p = p * f[j];   // noise_reduction.comp:57
             b[j] = low[j] + p;      // img_addition.comp:15
         }
-        store8(ob, g.off + (uint32_t)(2 * kk + ph) * rb, b);
+        store8_nt(ob, g.off + (uint32_t)(2 * kk + ph) * rb, b);   // non-temporal since round 4: with steps in flight -2 % per step at 8 x 2048^2 (k_grad_apply has the numbers)
         if (GH) {
             const uint32_t dark = le_t >> (8 * ph);
             const uint32_t y = (uint32_t)(2 * kk + ph);
