@@ -252,20 +252,16 @@ __global__ void k_sqrt(const uint16_t* __restrict__ px, float* __restrict__ out,
 // cov = (imageSize / 512) * 512: the part of the grid the reference's dispatch covers (src/vk_processing.cpp:2293-2295).
 // Software-pipelined form: one row per trip; the raw row of trip y+1 is requested before trip y is
 // computed and squared only when it enters the window (so the request never blocks the arithmetic).
+// one workgroup of the march: `band` / `sdev` / `hist` are the image's own planes and histogram, `tile` its strip and block of four segments
 template <bool HIST, bool A8>
-__global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
-                                                                size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov,
-                                                                int rows_per_wave, int swz) {
-    __shared__ uint32_t lh[kHistLdsWords];
+__device__ __forceinline__ void sdev_march_block(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch, size_t plane,
+                                                 uint32_t* __restrict__ hist, int cov, int rows_per_wave, const Tile tile, uint32_t* lh) {
     hist_lds_clear(lh);
     __syncthreads();
-    const int img = blockIdx.z;
-    const Buf bb = make_buf(band + (size_t)img * plane, plane * 4);
+    const Buf bb = make_buf(band, plane * 4);
     const bool store = sdev != nullptr;   // nullptr: histogram only (the level's expand launch computes sdev itself, k_expand_fast<.., SD>)
-    if (store) sdev += (size_t)img * plane;
     const Buf db = make_buf(store ? sdev : band, store ? plane * 4 : 0);
     const int lane = threadIdx.x & 63;
-    const Tile tile = xcd_tile(swz);
     const int seg = __builtin_amdgcn_readfirstlane((int)(tile.segblock * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
     const int y0 = seg * rows_per_wave;
     const SCfg g = make_scfg(tile.strip, lane, S);
@@ -296,8 +292,17 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __r
     }
     if (HIST) {
         __syncthreads();
-        hist_lds_flush(lh, hist + (size_t)img * hist_stride);
+        hist_lds_flush(lh, hist);
     }
+}
+template <bool HIST, bool A8>
+__global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
+                                                                size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov,
+                                                                int rows_per_wave, int swz) {
+    __shared__ uint32_t lh[kHistLdsWords];
+    const size_t img = blockIdx.z;
+    sdev_march_block<HIST, A8>(band + img * plane, sdev ? sdev + img * plane : nullptr, S, pitch, plane, HIST ? hist + img * hist_stride : nullptr, cov, rows_per_wave,
+                               xcd_tile(swz), lh);
 }
 
 // ---- K10 + K11, one 16-row histogram run per workgroup ------------------------------------------------------
@@ -411,6 +416,38 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_runs(const SdevRunL
     tile.segblock = local / l.strips;
     const size_t img = blockIdx.z;
     sdev_run_block<A8>(l.band + img * l.plane, l.sdev ? l.sdev + img * l.plane : nullptr, l.S, l.pitch, l.plane, l.hist + img * hist_stride, cov, tile, lh, nzw);
+}
+
+// EVERY level's sdev + noise-histogram pass in one launch, each level in the form its launch of its own would take (a march of l.rows rows per
+// wavefront, or one 16-row run per workgroup where l.rows == 0). The four passes of a step depend on nothing but their own band image, and
+// alone on the chip the marches of levels 0 and 1 are 2 and 1 wavefronts per SIMD of dependent arithmetic (8 x 2048^2: 45 + 23 us, and 14 us
+// for the runs of levels 2 + 3): side by side they fill each other's issue slots.
+template <bool A8>
+__global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_levels(const SdevRunLevels a, size_t hist_stride, int cov) {
+    __shared__ uint32_t lh[kHistLdsWords];
+    __shared__ unsigned long long nzw[kWavesPerBlock][8];
+    int k = 0;
+    for (int j = 1; j < a.n; j++) k = (int)blockIdx.x >= a.l[j].first ? j : k;   // block-uniform
+    const SdevRunLevel& l = a.l[k];
+    const int local = (int)blockIdx.x - l.first;
+    // a level starts at a multiple of 8 workgroups and the grid is a multiple of 8 wide (the launcher pads), so workgroup `local` of a level
+    // runs on XCD local % 8: the mapping of xcd_tile() — XCD x takes the x-th eighth of the level's blocks, strip by strip — where the blocks
+    // divide by 8, the plain one elsewhere
+    const int blocks = l.blocks;
+    Tile tile;
+    if (a.swz && (blocks & 7) == 0) {
+        const int xcd = local & 7, j = local >> 3;
+        tile.strip = j % l.strips;
+        tile.segblock = xcd * (blocks >> 3) + j / l.strips;
+    } else {
+        tile.strip = local % l.strips;
+        tile.segblock = local / l.strips;
+    }
+    if (tile.segblock >= blocks) return;   // padding (block-uniform)
+    const size_t img = blockIdx.z;
+    float* sd = l.sdev ? l.sdev + img * l.plane : nullptr;
+    if (l.rows > 0) sdev_march_block<true, A8>(l.band + img * l.plane, sd, l.S, l.pitch, l.plane, l.hist + img * hist_stride, cov, l.rows, tile, lh);
+    else sdev_run_block<A8>(l.band + img * l.plane, sd, l.S, l.pitch, l.plane, l.hist + img * hist_stride, cov, tile, lh, nzw);
 }
 
 // histogram only (kernel-level parity tests feed a foreign sdev image): same scan, no stencil.
@@ -789,14 +826,38 @@ void launch_sdev_hist_runs(hipStream_t st, int n, const float* const* band, floa
     for (int k = 0; k < n; k++) {
         const LevelDesc& l = lv[k];
         const int strips = (l.S + kStripCols - 1) / kStripCols;
-        a.l[k] = SdevRunLevel{band[k], sdev[k], hist[k], l.plane, l.S, l.pitch, strips, first};
+        a.l[k] = SdevRunLevel{band[k], sdev[k], hist[k], l.plane, l.S, l.pitch, strips, first, 0, 0};
         first += strips * ((l.S + kHistArea - 1) / kHistArea);
         a8 = a8 && (l.S & 7) == 0;
     }
     for (int k = n; k < kSdevRunLevelsMax; k++) a.l[k] = a.l[0];
+    a.swz = 0;
     const dim3 grid(first, 1, batch);
     if (a8) hipLaunchKernelGGL((k_sdev_hist_runs<true>), grid, dim3(kBlockThreads), 0, st, a, hist_stride, cov);
     else hipLaunchKernelGGL((k_sdev_hist_runs<false>), grid, dim3(kBlockThreads), 0, st, a, hist_stride, cov);
+}
+
+void launch_sdev_hist_levels(hipStream_t st, int n, const float* const* band, float* const* sdev, const LevelDesc* lv, uint32_t* const* hist,
+                             const int* rows, size_t hist_stride, int cov, int batch) {
+    SdevRunLevels a;
+    a.n = n;
+    int first = 0;
+    bool a8 = true;
+    for (int k = 0; k < n; k++) {
+        const LevelDesc& l = lv[k];
+        const int strips = (l.S + kStripCols - 1) / kStripCols;
+        int blocks;   // workgroups per strip
+        if (rows[k] > 0) { const int segs = (l.S + rows[k] - 1) / rows[k]; blocks = (segs + kWavesPerBlock - 1) / kWavesPerBlock; }
+        else blocks = (l.S + kHistArea - 1) / kHistArea;
+        a.l[k] = SdevRunLevel{band[k], sdev[k], hist[k], l.plane, l.S, l.pitch, strips, first, rows[k] > 0 ? rows[k] : 0, blocks};
+        first += (strips * blocks + 7) & ~7;   // every level starts on XCD 0
+        a8 = a8 && (l.S & 7) == 0;
+    }
+    for (int k = n; k < kSdevRunLevelsMax; k++) a.l[k] = a.l[0];
+    a.swz = xcd_swizzle_on();
+    const dim3 grid(first, 1, batch);
+    if (a8) hipLaunchKernelGGL((k_sdev_hist_levels<true>), grid, dim3(kBlockThreads), 0, st, a, hist_stride, cov);
+    else hipLaunchKernelGGL((k_sdev_hist_levels<false>), grid, dim3(kBlockThreads), 0, st, a, hist_stride, cov);
 }
 
 // sdev alone (no histogram): the stored image of a level whose hot path does not store it, for getters / dumps / the stage entry points

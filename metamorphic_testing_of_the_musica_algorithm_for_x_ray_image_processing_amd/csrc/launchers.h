@@ -87,6 +87,10 @@ void launch_sdev_hist(hipStream_t st, const float* band, float* sdev, const Leve
 // the 16-row-run form of launch_sdev_hist for n <= kSdevRunLevelsMax levels in ONE launch (hist[k]: image 0's histogram of level k)
 void launch_sdev_hist_runs(hipStream_t st, int n, const float* const* band, float* const* sdev, const LevelDesc* lv, uint32_t* const* hist,
                            size_t hist_stride, int cov, int batch);
+// every level's sdev + noise-histogram pass in ONE launch, each level in its own form (rows[k] > 0: the march with that many rows per
+// wavefront, 0: one 16-row run per workgroup); sdev[k] == nullptr: histogram only
+void launch_sdev_hist_levels(hipStream_t st, int n, const float* const* band, float* const* sdev, const LevelDesc* lv, uint32_t* const* hist,
+                             const int* rows, size_t hist_stride, int cov, int batch);
 void launch_noise_hist_only(hipStream_t st, const float* sdev, const LevelDesc& l, uint32_t* hist, size_t hist_stride, int cov, int batch);
 // img_sdev.comp:10-35 with the 25 squares accumulated in the shader's order (one thread per texel; MUSICA_FLAG_REFERENCE_ORDER)
 void launch_sdev_literal(hipStream_t st, const float* band, float* sdev, const LevelDesc& l, int batch);

@@ -121,6 +121,7 @@ struct musica_ctx {
     // noise-histogram launches of those levels store nothing: 8 of a step's 48 bytes per input pixel. The whole-step scripts run that way
     // (sd_active); the stage entry points, getters and dumps want the stored images: ensure_sdev() writes them on demand.
     bool sd_fused, sd_active, sdev_stored;
+    bool sdev_one_launch;      // the sdev + noise-histogram passes of levels 0 .. 3 as ONE launch (k_sdev_hist_levels); MUSICA_SDEV_ONE_LAUNCH=0: one launch per marching level + one for the runs
     int rows_rb[MUSICA_MAX_LEVELS];   // its coarse rows per wavefront
     musica_hist_max_point* d_grad_max;
     DevCurve* d_gcurve;
@@ -450,6 +451,10 @@ static musica_ctx* create_impl(const musica_params* params, const musica_tunable
         c->sd_fused = env_int("MUSICA_SDEV_IN_EXPAND", pays ? 1 : 0) != 0 && !c->generic;
     }
     c->sd_active = false; c->sdev_stored = true;
+    // every level's sdev pass in one launch for batches and for the contexts of a pipeline (same-box A/B: a lone 8 x 2048^2 context -3.5 %, 8192^2 -1.1 %;
+    // three steps in flight 8 x 2048^2 -1 %, 8192^2 -1.5 %, 3072^2 L12 -3.5 %); a lone context with one image keeps one launch per marching level:
+    // beside the reduce tail of its two-stream script the merged launch slows the tail's small launches (3072^2 L12 +4 %, 2048^2 +0.7 %)
+    c->sdev_one_launch = env_int("MUSICA_SDEV_ONE_LAUNCH", ((params->flags & MUSICA_FLAG_LINEAR) || c->B > 1) ? 1 : 0) != 0;
     c->fuse_gh = env_int("MUSICA_FUSE_GH", 1) != 0 && c->fuse_u16 && (!(params->flags & MUSICA_FLAG_CLAHE) || c->clahe_raw) &&
                  cnr_scale(c->lv[0].S, c->lv[MUSICA_CNR_LEVEL].S) == 8;
     tick.lap("streams + events");
@@ -680,8 +685,30 @@ static int sdev_runs_from(const musica_ctx* c) {
     while (first > 0 && c->rows_sdev[first - 1] <= 0) first--;
     return first;
 }
+// every level's sdev + noise-histogram pass in one launch, each level in its own form (k_sdev_hist_levels)
+static void run_sdev_all_levels(musica_ctx* c) {
+    const float* band[kSdevRunLevelsMax];
+    float* sdev[kSdevRunLevelsMax];
+    uint32_t* hist[kSdevRunLevelsMax];
+    LevelDesc lv[kSdevRunLevelsMax];
+    int rows[kSdevRunLevelsMax];
+    int n = 0;
+    for (int i = 0; i <= MUSICA_CNR_LEVEL; i++, n++) {
+        band[n] = c->d_band[i]; sdev[n] = sd_level(c, i) ? nullptr : c->d_sdev[i]; lv[n] = c->lv[i];
+        hist[n] = c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS;
+        rows[n] = c->rows_sdev[i] > 0 ? c->rows_sdev[i] : 0;
+    }
+    launch_sdev_hist_levels(c->cur, n, band, sdev, lv, hist, rows, (size_t)4 * MUSICA_NOISE_BINS, c->hist_cov, c->B);
+}
 static void enqueue_analysis(musica_ctx* c, hipStream_t st = nullptr) {
     if (!st) st = c->stream;
+    if (c->sdev_one_launch && !c->ref_order && !c->tuning) {
+        { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_all_levels(c); }
+        Span sp2(c, MUSICA_KERNEL_CURVES);
+        launch_curves_cnr(st, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
+                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_thr090);
+        return;
+    }
     int merged = sdev_runs_from(c);
     if (merged >= MUSICA_CNR_LEVEL) merged = MUSICA_CNR_LEVEL + 1;   // one level is its own launch
     for (int i = 0; i < merged; i++) {  // i < coarserLevelsStart || i <= cnrLevel, :2285

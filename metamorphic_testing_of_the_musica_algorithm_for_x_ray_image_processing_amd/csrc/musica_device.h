@@ -87,10 +87,13 @@ struct SdevRunLevel {
     uint32_t* hist;   // image 0's histogram of this level
     size_t plane;
     int S, pitch, strips, first;
+    int rows;         // k_sdev_hist_levels: rows per wavefront of a level that marches, 0 for a level that takes one 16-row run per workgroup
+    int blocks;       // k_sdev_hist_levels: workgroups per strip
 };
 struct SdevRunLevels {
     SdevRunLevel l[kSdevRunLevelsMax];
     int n;
+    int swz;          // k_sdev_hist_levels: XCD-aware workgroup -> tile mapping inside a level
 };
 
 // the levels of one k_tiny_tail launch (kernels_pyramid.hip): level T + k reads `fine`, writes its reduced image `down`, its

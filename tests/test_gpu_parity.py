@@ -175,6 +175,8 @@ def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"MUSICA_FUSE_GH": "0"}, {"MUSICA_XCD_SWIZZLE": "0"}, {"MUSICA_GRAD_ONE_LAUNCH": "0"}, {"MUSICA_TINY_TAIL": "0"},
+                                 {"MUSICA_SDEV_ONE_LAUNCH": "1"}, {"MUSICA_SDEV_ONE_LAUNCH": "1", "MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "0", "MUSICA_SDEV_IN_EXPAND": "1"},
+                                 {"MUSICA_SDEV_ONE_LAUNCH": "1", "MUSICA_XCD_SWIZZLE": "0", "MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "0"}, {"MUSICA_SDEV_ONE_LAUNCH": "0", "MUSICA_SDEV_IN_EXPAND": "1"},
                                  {"MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "0"}, {"MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "1"},
                                  {"MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "1"}, {"MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "3"}, {"MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "4"}, {"MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "64"},
                                  {"MUSICA_AUTOTUNE": "0", "MUSICA_RB_ROWS": "5", "MUSICA_EXPAND_ROWS": "2", "MUSICA_SDEV_ROWS": "16"},
