@@ -252,49 +252,7 @@ __global__ void k_sqrt(const uint16_t* __restrict__ px, float* __restrict__ out,
 // cov = (imageSize / 512) * 512: the part of the grid the reference's dispatch covers (src/vk_processing.cpp:2293-2295).
 // Software-pipelined form: one row per trip; the raw row of trip y+1 is requested before trip y is
 // computed and squared only when it enters the window (so the request never blocks the arithmetic).
-// one workgroup of the march: `band` / `sdev` / `hist` are the image's own planes and histogram, `tile` its strip and block of four segments
-template <bool HIST, bool A8>
-__device__ __forceinline__ void sdev_march_block(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch, size_t plane,
-                                                 uint32_t* __restrict__ hist, int cov, int rows_per_wave, const Tile tile, uint32_t* lh) {
-    hist_lds_clear(lh);
-    __syncthreads();
-    const Buf bb = make_buf(band, plane * 4);
-    const bool store = sdev != nullptr;   // nullptr: histogram only (the level's expand launch computes sdev itself, k_expand_fast<.., SD>)
-    const Buf db = make_buf(store ? sdev : band, store ? plane * 4 : 0);
-    const int lane = threadIdx.x & 63;
-    const int seg = __builtin_amdgcn_readfirstlane((int)(tile.segblock * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
-    const int y0 = seg * rows_per_wave;
-    const SCfg g = make_scfg(tile.strip, lane, S);
-    const uint32_t rb = (uint32_t)pitch * 4u;
-    auto roff = [&](int row) -> uint32_t { return (row >= 0 && row < S) ? (uint32_t)row * rb : kOob; };
-    if (y0 < S) {
-        const int y1 = min(y0 + rows_per_wave, S);
-        // (Five window slots used round-robin in a trip unrolled five times — no `w0 = w1; ...` copies, 68 of the 284 vector
-        // instructions of a row — was measured and dropped: 116 registers instead of 96, 4 wavefronts per SIMD instead of 5,
-        // and the launch is 6 % slower. Two or four raw rows in flight per wavefront instead of one: no change either.)
-        SRow w0, w1, w2, w3, w4;
-        SRaw raw;
-        load_srow<A8>(w0, bb, roff(y0 - 2), g, S);
-        load_srow<A8>(w1, bb, roff(y0 - 1), g, S);
-        load_srow<A8>(w2, bb, roff(y0), g, S);
-        load_srow<A8>(w3, bb, roff(y0 + 1), g, S);
-        load_sraw(raw, bb, roff(y0 + 2), g);
-        unsigned long long alive[8], start[8];
-        sdev_start_masks(start, alive, g, cov);
-        for (int y = y0; y < y1; y++) {
-            square_srow<A8>(w4, raw, g, S);
-            // rows past the image carry an out-of-range offset: no access. (Non-temporal loads for the rows no neighbouring segment reads,
-            // the trick that took 7 % off the metric kernel, change nothing here: 8 x 2048^2 33.6 - 37.7 us either way, 8192^2 55 -> 62 us.)
-            load_sraw(raw, bb, roff(y + 3), g);
-            sdev_row<HIST, A8>(w0, w1, w2, w3, w4, g, S, y, cov, store ? sdev + (size_t)y * pitch : nullptr, db, (uint32_t)y * rb, lh, alive, start, store);
-            w0 = w1; w1 = w2; w2 = w3; w3 = w4;
-        }
-    }
-    if (HIST) {
-        __syncthreads();
-        hist_lds_flush(lh, hist);
-    }
-}
+// (sdev_march_block — one workgroup of the march — lives in sdev_parts.h: the paired reduce + band / sdev launch of kernels_expand_sd.hip uses it too)
 template <bool HIST, bool A8>
 __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
                                                                 size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov,
@@ -314,83 +272,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_pf(const float* __r
 // column — the run of a column is alive at row r exactly when every earlier row of the run had a non-zero bin — and add
 // their texels to the workgroup's LDS histogram. Same expressions (sdev_values, musica_noise_bin) as the march: same bits.
 // Input rows are read twice (8 per 4 instead of 20 per 16), from the XCD's L2 the second time.
-constexpr int kRunRowsPerWave = kHistArea / kWavesPerBlock;   // 4
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-// one run: `band` / `sdev` / `hist` are the image's own plane and histogram, `tile` the run's 512-column strip and 16-row block
-template <bool A8>
-__device__ __forceinline__ void sdev_run_block(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch, size_t plane,
-                                               uint32_t* __restrict__ hist, int cov, const Tile tile, uint32_t* lh,
-                                               unsigned long long (*nzw)[8]) {
-    hist_lds_clear(lh);
-    const Buf bb = make_buf(band, plane * 4);
-    const bool store = sdev != nullptr;   // nullptr: histogram only
-    const Buf db = make_buf(store ? sdev : band, store ? plane * 4 : 0);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int y0 = tile.segblock * kHistArea + wave * kRunRowsPerWave;   // wave-uniform
-    const SCfg g = make_scfg(tile.strip, lane, S);
-    const uint32_t rb = (uint32_t)pitch * 4u;
-    auto roff = [&](int row) -> uint32_t { return (row >= 0 && row < S) ? (uint32_t)row * rb : kOob; };
-    unsigned long long nz[kRunRowsPerWave][8];
-    int bin[kRunRowsPerWave][8];
-    unsigned long long mine[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) mine[j] = ~0ull;
-    const int nrows = min(max(S - y0, 0), kRunRowsPerWave);   // rows of this wavefront inside the image
-    if (nrows > 0) {
-        SRaw raw[kRunRowsPerWave + 4];
-#pragma unroll
-        for (int k = 0; k < kRunRowsPerWave + 4; k++) load_sraw(raw[k], bb, roff(y0 - 2 + k), g);
-        SRow w[kRunRowsPerWave + 4];
-#pragma unroll
-        for (int k = 0; k < kRunRowsPerWave + 4; k++) square_srow<A8>(w[k], raw[k], g, S);
-#pragma unroll
-        for (int r = 0; r < kRunRowsPerWave; r++) {
-            if (r < nrows) {   // wave-uniform
-                float s[8];
-                sdev_values(w[r], w[r + 1], w[r + 2], w[r + 3], w[r + 4], g, s);
-                if (store) sdev_store<A8>(s, g, sdev + (size_t)(y0 + r) * pitch, db, (uint32_t)(y0 + r) * rb);
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    bin[r][j] = musica_noise_bin(s[j]);      // 0 = break (noise_hist.comp:29, :33, :39)
-                    nz[r][j] = __ballot(bin[r][j] != 0);
-                    mine[j] &= nz[r][j];
-                }
-            }
-        }
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) nzw[wave][j] = mine[j];
-    }
-    __syncthreads();   // the cleared histogram and every wavefront's masks
-    if (nrows > 0 && y0 < cov) {   // the dispatch covers whole runs (cov is a multiple of 512)
-        const uint32_t copy_b = (uint32_t)((lane % kHistCopies) * kHistCopyStride) * 4u, scratch_b = (uint32_t)(kHistCopies * kHistCopyStride + lane) * 4u;
-        unsigned long long alive[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            alive[j] = __ballot(j < g.valid && g.c + j < cov);   // columns outside the image / the coverage start dead
-            for (int v = 0; v < wave; v++) alive[j] &= uniform64(nzw[v][j]);   // the same value in every lane: back into scalar registers
-        }
-#pragma unroll
-        for (int r = 0; r < kRunRowsPerWave; r++) {
-            if (r < nrows) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    alive[j] &= nz[r][j];
-                    const uint32_t addr = select_by_lane_mask(alive[j], copy_b + (uint32_t)bin[r][j] * 4u, scratch_b);
-                    atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lh) + addr), 1u);   // :45
-                }
-            }
-        }
-    }
-    __syncthreads();
-    hist_lds_flush(lh, hist);
-}
-
+// (sdev_run_block lives in sdev_parts.h, like sdev_march_block)
 template <bool A8>
 __global__ __launch_bounds__(kBlockThreads) void k_sdev_hist_run(const float* __restrict__ band, float* __restrict__ sdev, int S, int pitch,
                                                                  size_t plane, uint32_t* __restrict__ hist, size_t hist_stride, int cov, int swz) {

@@ -496,18 +496,18 @@ __device__ __forceinline__ void load_f(FRow& r, const Buf& b, uint32_t row_off, 
 // U16: the fine image is the raw uint16 input, normalised on the fly (level 0); the two rows of the next trip are requested as
 // raw pixels (6 registers) one trip ahead. Otherwise the fine image is f32 (levels >= 1): the rows are loaded where they are
 // needed (a prefetch would cost 24 registers and a wavefront per SIMD; these levels are small and L2-resident).
+// one workgroup of the launch: `tile` = its strip and block of four segments, `img` = its image (k_reduce_band below; the paired launch of
+// kernels_expand_sd.hip gives some of its workgroups this role)
 template <bool U16>
-__global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __restrict__ fine, float* __restrict__ down, float* __restrict__ band,
-                                                               int S, int pitch, size_t plane, int Sc, int cpitch, size_t cplane,
-                                                               int rows_per_wave, const uint32_t* __restrict__ minmax, int min_chain_exact,
-                                                               uint16_t* __restrict__ le090, int swz) {
+__device__ __forceinline__ void reduce_band_block(const void* __restrict__ fine, float* __restrict__ down, float* __restrict__ band,
+                                                  int S, int pitch, size_t plane, int Sc, int cpitch, size_t cplane,
+                                                  int rows_per_wave, const uint32_t* __restrict__ minmax, int min_chain_exact,
+                                                  uint16_t* __restrict__ le090, const Tile tile, const int img) {
     const int lane = threadIdx.x & 63;
-    const Tile tile = xcd_tile(swz);
     const int seg = __builtin_amdgcn_readfirstlane((int)(tile.segblock * kWavesPerBlock + (threadIdx.x >> 6)));   // wave-uniform: row arithmetic stays on the scalar unit
     const int k0 = seg * rows_per_wave;
     if (k0 >= Sc) return;  // wave-uniform
     const int k1 = min(k0 + rows_per_wave, Sc);
-    const int img = blockIdx.z;
     NormK nk = make_norm(0.0f, 1.0f);
     if (U16) {
         float minv, maxv;
@@ -579,6 +579,13 @@ __global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __
         if (want_mask) bstore_u16(mb, moff + (uint32_t)(Sc - 1) * mrb, le090_bits(w0, w1));
         band_pair(cm2, cm1, cm1, w0, w1, g, bb, (uint32_t)(2 * (Sc - 1)) * rb, (uint32_t)(2 * (Sc - 1) + 1) * rb);
     }
+}
+template <bool U16>
+__global__ __launch_bounds__(kBlockThreads, 4) void k_reduce_band(const void* __restrict__ fine, float* __restrict__ down, float* __restrict__ band,
+                                                               int S, int pitch, size_t plane, int Sc, int cpitch, size_t cplane,
+                                                               int rows_per_wave, const uint32_t* __restrict__ minmax, int min_chain_exact,
+                                                               uint16_t* __restrict__ le090, int swz) {
+    reduce_band_block<U16>(fine, down, band, S, pitch, plane, Sc, cpitch, cplane, rows_per_wave, minmax, min_chain_exact, le090, xcd_tile(swz), (int)blockIdx.z);
 }
 
 // lowpass value at fine (x, y) for any S (generic form).
@@ -1223,6 +1230,54 @@ static inline dim3 stream_grid(int S, int rows, int rows_per_wave, int batch) {
 }
 
 #ifndef MUSICA_PYRAMID_FULL
+// Two launches that depend on the same producer and not on each other, as one: the sdev + noise-histogram pass of level i and reduce + band of
+// level i + 1 both wait for reduce + band of level i only. Alone on the chip each is 1 - 2 wavefronts per SIMD of dependent arithmetic (8 x 2048^2:
+// 45 us and 20 us at i = 0); as the two roles of one grid they fill each other's issue slots, and the pyramid's dependent chain RB1 -> RB2 -> RB3 -> RB4
+// runs in the shadow of the sdev passes instead of in front of them. A role is a contiguous range of workgroups starting at a multiple of 8 (the XCD a
+// workgroup runs on is its index % 8: the tile mapping of xcd_tile() holds inside a role).
+__device__ __forceinline__ bool role_tile(int local, int strips, int blocks, int swz, Tile& t) {
+    if (swz && (blocks & 7) == 0) {
+        const int xcd = local & 7, j = local >> 3;
+        t.strip = j % strips;
+        t.segblock = xcd * (blocks >> 3) + j / strips;
+    } else {
+        t.strip = local % strips;
+        t.segblock = local / strips;
+    }
+    return t.segblock < blocks;   // false: padding
+}
+__global__ __launch_bounds__(kBlockThreads, 4) void k_rb_sdev(const RbSdevArgs a) {
+    __shared__ uint32_t lh[kHistLdsWords];
+    __shared__ unsigned long long nzw[kWavesPerBlock][8];
+    const int img = (int)blockIdx.z;
+    Tile tile;
+    if ((int)blockIdx.x >= a.rb_first) {   // block-uniform
+        if (!role_tile((int)blockIdx.x - a.rb_first, a.rb_strips, a.rb_blocks, a.swz, tile)) return;
+        reduce_band_block<false>(a.fine, a.down, a.band, a.S, a.pitch, a.plane, a.Sc, a.cpitch, a.cplane, a.rows_rb, nullptr, 0, nullptr, tile, img);
+        return;
+    }
+    const SdevRunLevel& l = a.sl;
+    if (!role_tile((int)blockIdx.x, l.strips, l.blocks, a.swz, tile)) return;
+    float* sd = l.sdev ? l.sdev + (size_t)img * l.plane : nullptr;
+    if (l.rows > 0) sdev_march_block<true, true>(l.band + (size_t)img * l.plane, sd, l.S, l.pitch, l.plane, l.hist + (size_t)img * a.hist_stride, a.cov, l.rows, tile, lh);
+    else sdev_run_block<true>(l.band + (size_t)img * l.plane, sd, l.S, l.pitch, l.plane, l.hist + (size_t)img * a.hist_stride, a.cov, tile, lh, nzw);
+}
+// `a`: the pointers, geometry of the reduce + band role and sl.{band, sdev, hist, rows} filled in by the caller; ls: the sdev level
+void launch_rb_sdev(hipStream_t st, RbSdevArgs a, const LevelDesc& ls, int batch) {
+    const int s_strips = (ls.S + kStripCols - 1) / kStripCols;
+    int s_blocks;
+    if (a.sl.rows > 0) { const int segs = (ls.S + a.sl.rows - 1) / a.sl.rows; s_blocks = (segs + kWavesPerBlock - 1) / kWavesPerBlock; }
+    else s_blocks = (ls.S + kHistArea - 1) / kHistArea;
+    a.sl.plane = ls.plane; a.sl.S = ls.S; a.sl.pitch = ls.pitch; a.sl.strips = s_strips; a.sl.blocks = s_blocks; a.sl.first = 0;
+    a.rb_first = (s_strips * s_blocks + 7) & ~7;
+    a.rb_strips = (a.S + kStripCols - 1) / kStripCols;
+    const int segs = (a.Sc + a.rows_rb - 1) / a.rows_rb;
+    a.rb_blocks = (segs + kWavesPerBlock - 1) / kWavesPerBlock;
+    a.swz = xcd_swizzle_on();
+    const int total = a.rb_first + ((a.rb_strips * a.rb_blocks + 7) & ~7);
+    hipLaunchKernelGGL(k_rb_sdev, dim3(total, 1, batch), dim3(kBlockThreads), 0, st, a);
+}
+
 // The expand launch of a level whose sdev image is not stored (a.sdev == nullptr; GAIN_CURVE levels 0 .. 2): kernels_pyramid.hip's
 // launch_expand hands those over to this translation unit.
 void launch_expand_sd(hipStream_t st, const ExpandArgs& a, bool nr, int batch) {

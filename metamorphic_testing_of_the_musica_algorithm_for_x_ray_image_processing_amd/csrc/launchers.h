@@ -69,6 +69,16 @@ void launch_reduce_band_u16(hipStream_t st, const uint16_t* px, float* down, flo
 void launch_reduce_band(hipStream_t st, const float* fine, float* down, float* band, const LevelDesc& lf, const LevelDesc& lc, int batch, int rows_per_wave);
 void launch_lowpass(hipStream_t st, const float* coarse, float* low, const LevelDesc& lf, const LevelDesc& lc, int batch, int ref = 0);
 void launch_expand(hipStream_t st, const ExpandArgs& a, int gain_mode, bool nr, int batch, bool force_generic);
+// reduce + band of level i + 1 AND the sdev + noise-histogram pass of level i in one launch (both read what the reduce + band launch of level i wrote
+// and nothing of each other; kernels_expand_sd.hip). Workgroups 0 .. of grid.x take the sdev pass (sl.first = 0), the rest the reduce + band launch.
+struct RbSdevArgs {
+    const float* fine; float* down; float* band;   // reduce + band of level i + 1: its fine image, coarse image, band image
+    int S, pitch; size_t plane; int Sc, cpitch; size_t cplane; int rows_rb;
+    int rb_strips, rb_blocks, rb_first;            // that role's workgroups: rb_strips * rb_blocks from rb_first on (a multiple of 8)
+    SdevRunLevel sl;                               // level i's pass: march (sl.rows > 0) or one run per workgroup; sl.sdev == nullptr: histogram only
+    size_t hist_stride; int cov, swz;
+};
+void launch_rb_sdev(hipStream_t st, RbSdevArgs a, const LevelDesc& ls, int batch);
 void launch_expand_sd(hipStream_t st, const ExpandArgs& a, bool nr, int batch);   // a.sdev == nullptr: sdev computed by the launch (kernels_expand_sd.hip)
 // reduce + band of the levels in `a`, then their expand slots, one workgroup per image (levels of side <= kTailSide)
 void launch_tiny_tail(hipStream_t st, const TailArgs& a, int batch);

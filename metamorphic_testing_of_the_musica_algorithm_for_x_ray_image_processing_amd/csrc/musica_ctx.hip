@@ -121,6 +121,7 @@ struct musica_ctx {
     // noise-histogram launches of those levels store nothing: 8 of a step's 48 bytes per input pixel. The whole-step scripts run that way
     // (sd_active); the stage entry points, getters and dumps want the stored images: ensure_sdev() writes them on demand.
     bool sd_fused, sd_active, sdev_stored;
+    bool pair_rb_sdev;         // the one-stream script pairs the sdev pass of level i with reduce + band of level i + 1 in one launch (k_rb_sdev); MUSICA_PAIR_RB_SDEV
     bool sdev_one_launch;      // the sdev + noise-histogram passes of levels 0 .. 3 as ONE launch (k_sdev_hist_levels); MUSICA_SDEV_ONE_LAUNCH=0: one launch per marching level + one for the runs
     int rows_rb[MUSICA_MAX_LEVELS];   // its coarse rows per wavefront
     musica_hist_max_point* d_grad_max;
@@ -454,6 +455,10 @@ static musica_ctx* create_impl(const musica_params* params, const musica_tunable
     // every level's sdev pass in one launch for batches and for the contexts of a pipeline (same-box A/B: a lone 8 x 2048^2 context -3.5 %, 8192^2 -1.1 %;
     // three steps in flight 8 x 2048^2 -1 %, 8192^2 -1.5 %, 3072^2 L12 -3.5 %); a lone context with one image keeps one launch per marching level:
     // beside the reduce tail of its two-stream script the merged launch slows the tail's small launches (3072^2 L12 +4 %, 2048^2 +0.7 %)
+    // the pairs of the one-stream script (k_rb_sdev) for the contexts of a pipeline from 2 x 2048^2 texels per step (same-box A/B, three steps in flight:
+    // 8 x 2048^2 -3.1 %, 8192^2 -2.0 %, 4096^2 + CLAHE -2.1 %, 3072^2 L12 +0.6 %, one 2048^2 image +2.8 %); a lone one-stream context is slower with them
+    // (512^2 +17 %, 1024^2 +3 %, 1536^2 +7 %, 2 / 4 x 1024^2 +5 / +4 %): alone on the chip a pair costs what its two launches cost one after the other
+    c->pair_rb_sdev = env_int("MUSICA_PAIR_RB_SDEV", ((params->flags & MUSICA_FLAG_LINEAR) && (size_t)c->B * N * N >= (size_t)2 * 2048 * 2048) ? 1 : 0) != 0;
     c->sdev_one_launch = env_int("MUSICA_SDEV_ONE_LAUNCH", ((params->flags & MUSICA_FLAG_LINEAR) || c->B > 1) ? 1 : 0) != 0;
     c->fuse_gh = env_int("MUSICA_FUSE_GH", 1) != 0 && c->fuse_u16 && (!(params->flags & MUSICA_FLAG_CLAHE) || c->clahe_raw) &&
                  cnr_scale(c->lv[0].S, c->lv[MUSICA_CNR_LEVEL].S) == 8;
@@ -686,14 +691,14 @@ static int sdev_runs_from(const musica_ctx* c) {
     return first;
 }
 // every level's sdev + noise-histogram pass in one launch, each level in its own form (k_sdev_hist_levels)
-static void run_sdev_all_levels(musica_ctx* c) {
+static void run_sdev_all_levels(musica_ctx* c, int first = 0) {
     const float* band[kSdevRunLevelsMax];
     float* sdev[kSdevRunLevelsMax];
     uint32_t* hist[kSdevRunLevelsMax];
     LevelDesc lv[kSdevRunLevelsMax];
     int rows[kSdevRunLevelsMax];
     int n = 0;
-    for (int i = 0; i <= MUSICA_CNR_LEVEL; i++, n++) {
+    for (int i = first; i <= MUSICA_CNR_LEVEL; i++, n++) {
         band[n] = c->d_band[i]; sdev[n] = sd_level(c, i) ? nullptr : c->d_sdev[i]; lv[n] = c->lv[i];
         hist[n] = c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS;
         rows[n] = c->rows_sdev[i] > 0 ? c->rows_sdev[i] : 0;
@@ -829,7 +834,46 @@ static void enqueue_gradation(musica_ctx* c, bool fused) {
 }
 
 // One in-order stream, the order of the reference's command buffer (dag == 0).
+// reduce + band of level i + 1 and the sdev + noise-histogram pass of level i as one launch (k_rb_sdev): both wait for reduce + band of level i only
+static void run_rb_sdev_pair(musica_ctx* c, int i) {
+    const int r = i + 1;
+    RbSdevArgs a;
+    a.fine = level_input(c, r); a.down = c->d_down[r]; a.band = c->d_band[r];
+    a.S = c->lv[r].S; a.pitch = c->lv[r].pitch; a.plane = c->lv[r].plane;
+    a.Sc = c->lv[r + 1].S; a.cpitch = c->lv[r + 1].pitch; a.cplane = c->lv[r + 1].plane;
+    a.rows_rb = c->rows_rb[r];
+    a.sl.band = c->d_band[i]; a.sl.sdev = sd_level(c, i) ? nullptr : c->d_sdev[i];
+    a.sl.hist = c->d_noise_hist + (size_t)i * MUSICA_NOISE_BINS;
+    a.sl.rows = c->rows_sdev[i] > 0 ? c->rows_sdev[i] : 0;
+    a.hist_stride = (size_t)4 * MUSICA_NOISE_BINS; a.cov = c->hist_cov;
+    launch_rb_sdev(c->cur, a, c->lv[i], c->B);
+}
+// One in-order stream with the pairs: minmax RB0 [RB1 | S0] [RB2 | S1] [RB3 | S2] [RB4 | S3] RB5 .. [tail] curves+cnr E .. gradation — the pyramid's
+// dependent chain of ever smaller launches in the shadow of the sdev passes instead of in front of them.
+static void enqueue_linear_paired(musica_ctx* c) {
+    c->cur = c->stream;
+    enqueue_norm(c, true);
+    const int T = tail_first(c);
+    run_reduce_and_band(c, 0);
+    int i = 0;   // the first level whose sdev pass is still to run
+    while (i <= MUSICA_CNR_LEVEL && i + 1 < T && rb_level(c, i) && rb_level(c, i + 1)) {
+        Span sp(c, MUSICA_KERNEL_SDEV_HIST);
+        run_rb_sdev_pair(c, i);
+        i++;
+    }
+    for (int r = i + 1; r < T; r++) run_reduce_and_band(c, r);
+    if (T < c->L) run_tiny_tail(c, T);
+    if (i <= MUSICA_CNR_LEVEL) { Span sp(c, MUSICA_KERNEL_SDEV_HIST); run_sdev_all_levels(c, i); }
+    {
+        Span sp(c, MUSICA_KERNEL_CURVES);
+        launch_curves_cnr(c->stream, c->d_noise_hist, (size_t)4 * MUSICA_NOISE_BINS, c->d_noise_max, c->d_curves, c->d_cparams, c->L, c->B, c->d_luts,
+                          c->d_sdev[MUSICA_CNR_LEVEL], c->d_cnr, c->lv[MUSICA_CNR_LEVEL], c->d_minmax, c->min_chain_exact, c->d_thr090);
+    }
+    enqueue_expand(c, true, T - 1);
+    enqueue_gradation(c, true);
+}
 static void enqueue_linear(musica_ctx* c) {
+    if (c->pair_rb_sdev && !c->ref_order && !c->generic && !c->tuning) { enqueue_linear_paired(c); return; }
     c->cur = c->stream;
     enqueue_norm(c, true);   // with the clears of :2153-2162
     const int T = enqueue_reduce_from(c, 0);

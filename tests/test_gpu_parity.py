@@ -175,6 +175,8 @@ def test_dispatch_forms_give_the_same_bits(ob, batch, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"MUSICA_FUSE_GH": "0"}, {"MUSICA_XCD_SWIZZLE": "0"}, {"MUSICA_GRAD_ONE_LAUNCH": "0"}, {"MUSICA_TINY_TAIL": "0"},
+                                 {"MUSICA_STREAMS": "1", "MUSICA_PAIR_RB_SDEV": "1"}, {"MUSICA_STREAMS": "1", "MUSICA_PAIR_RB_SDEV": "1", "MUSICA_SDEV_IN_EXPAND": "1", "MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "0"},
+                                 {"MUSICA_STREAMS": "1", "MUSICA_PAIR_RB_SDEV": "1", "MUSICA_TINY_TAIL": "0", "MUSICA_XCD_SWIZZLE": "0"},
                                  {"MUSICA_SDEV_ONE_LAUNCH": "1"}, {"MUSICA_SDEV_ONE_LAUNCH": "1", "MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "0", "MUSICA_SDEV_IN_EXPAND": "1"},
                                  {"MUSICA_SDEV_ONE_LAUNCH": "1", "MUSICA_XCD_SWIZZLE": "0", "MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "0"}, {"MUSICA_SDEV_ONE_LAUNCH": "0", "MUSICA_SDEV_IN_EXPAND": "1"},
                                  {"MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "0"}, {"MUSICA_AUTOTUNE": "0", "MUSICA_SDEV_RUN": "1"},
@@ -689,7 +691,7 @@ def test_cli_drop_in(ob, tmp_path):
     assert r.returncode == 1 and "MAIN ERROR: the image data don't match the actual image size" in r.stderr
 
 
-@pytest.mark.parametrize("sd", ["0", "1"])
+@pytest.mark.parametrize("sd", ["0", "1", "1+pairs"])
 def test_steps_in_flight_on_three_contexts_are_the_lone_contexts_steps(ob, sd, monkeypatch):
     """musica_pipeline_*: steps alternate over three linear contexts without waiting for one another (what bench.py times);
     with sdev stored (sd = 0) and computed inside the expand launches (sd = 1: what the timed contexts of bench.py do).
@@ -698,10 +700,11 @@ def test_steps_in_flight_on_three_contexts_are_the_lone_contexts_steps(ob, sd, m
     rows (rank + index * world) come from the stats kernel itself."""
     from metamorphic_testing_of_the_musica_algorithm_for_x_ray_image_processing_amd import batch as mb
     n, levels, b, depth = 520, 5, 2, 3
-    monkeypatch.setenv("MUSICA_SDEV_IN_EXPAND", sd)
+    monkeypatch.setenv("MUSICA_SDEV_IN_EXPAND", sd[0])
+    monkeypatch.setenv("MUSICA_PAIR_RB_SDEV", "1" if sd.endswith("pairs") else "0")   # the pairs of the one-stream script (k_rb_sdev): what byte-bound pipeline contexts run
     px = [np.stack([phantom(n, 1000 + 10 * c + k) for k in range(b)]) for c in range(depth)]
     pipe = mp.MusicaPipeline(n, levels=levels, batch=b, depth=depth)
-    assert pipe.context(0).fuses_sdev() == (sd == "1")
+    assert pipe.context(0).fuses_sdev() == (sd[0] == "1")
     pipe.upload(px[0])
     stale = pipe.context(0)
     pipe.prime()
